@@ -1,0 +1,165 @@
+/* q3asr.h -- C ABI of libq3asr_hip.so: the MI355X (gfx950) backend for the Qwen3-ASR hot path of
+ * second-state/qwen3_asr_rs.  Plain pointers and sizes only; no C++ or torch types cross this line.
+ *
+ * Each entry point names the reference interface it replaces (file:line in the reference tree).
+ * A Rust `feature = "hip"` arm binds these with `extern "C"` exactly as src/backend/mlx/ffi.rs binds
+ * mlx-c (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; q3a_last_error() returns the message
+ *     (the reference's forward paths are infallible/panic, src/tensor.rs:228,232; its load paths
+ *     return anyhow::Result, src/inference.rs:34-65 -- the shim maps non-zero to panic!/bail!).
+ *   - an engine handle is thread-compatible (one host thread per handle / per GPU).
+ *   - host buffers are caller-owned and never retained after return.
+ *   - "utterance" = one independent clip; a batch of B utterances is the data-parallel unit
+ *     (new functionality whose semantics equal running the reference B times).
+ */
+#ifndef Q3ASR_H
+#define Q3ASR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct q3a_engine q3a_engine;
+
+/* Engine options. Zero-initialise, then override. */
+typedef struct q3a_opts {
+  int32_t precise;        /* 0: activations enter the MFMA as bf16, bf16 KV cache (default)
+                             1: activations split into bf16 hi+lo pairs (2 MFMAs per tile), fp32 KV cache:
+                                near-fp32 logits, used to separate kernel bugs from bf16 rounding        */
+  int32_t max_new_tokens; /* generation cap per utterance (reference: 4096, src/inference.rs:153); 0 -> 4096 */
+  int32_t use_graph;      /* 1: replay the decode step from a captured hipGraph (default 1 when 0/unset -> see q3a_opts_default) */
+  int32_t debug_taps;     /* 1: keep per-stage intermediate tensors readable through q3a_debug_read      */
+  int32_t reserved[12];
+} q3a_opts;
+
+/* Fill `o` with the defaults (precise=0, max_new_tokens=4096, use_graph=1, debug_taps=0). */
+void q3a_opts_default(q3a_opts* o);
+
+/* Model dimensions as parsed from config.json (replaces AsrConfig::from_file, src/config.rs:115-121). */
+typedef struct q3a_dims {
+  int32_t enc_d_model, enc_layers, enc_heads, enc_ffn, num_mel_bins, n_window, n_window_infer,
+      conv_channels, enc_output_dim, max_source_positions;
+  int32_t vocab_size, hidden_size, intermediate_size, dec_layers, num_q_heads, num_kv_heads, head_dim,
+      tie_word_embeddings, mrope_interleaved;
+  int32_t mrope_section[4];
+  float rms_norm_eps;
+  double rope_theta;
+} q3a_dims;
+
+/* ---- load -------------------------------------------------------------------------------------- */
+
+/* AsrInference::load (src/inference.rs:30-86): parse config.json, read model.safetensors or the
+ * sharded index (src/weights.rs:10-58), build the bf16 device weight arena on GPU `device`. */
+int32_t q3a_engine_create(const char* model_dir, int32_t device, const q3a_opts* opts, q3a_engine** out);
+
+/* Weight arena for multi-GPU replicas: pack on one rank, broadcast the bytes over RCCL/xGMI, and
+ * create every replica from its device copy (no file reads on the replicas besides config.json). */
+int32_t q3a_arena_bytes(const char* model_dir, uint64_t* bytes);
+int32_t q3a_arena_pack(const char* model_dir, void* host_dst, uint64_t bytes);
+/* `device_arena` stays owned by the caller and must outlive the engine. */
+int32_t q3a_engine_create_from_arena(const char* model_dir, int32_t device, void* device_arena, uint64_t bytes,
+                                     const q3a_opts* opts, q3a_engine** out);
+
+void q3a_engine_destroy(q3a_engine* e);
+/* Last error of `e` (or of the calling thread when e == NULL, e.g. after a failed create). */
+const char* q3a_last_error(const q3a_engine* e);
+int32_t q3a_get_dims(const q3a_engine* e, q3a_dims* out);
+
+/* ---- shape helpers (host integer arithmetic) --------------------------------------------------------- */
+/* mel frames for n samples: ceil(n/160) (src/mel.rs:51,83-84). */
+int64_t q3a_num_frames(int64_t n_samples);
+/* AudioEncoder::get_output_length (src/audio_encoder.rs:269-279). */
+int32_t q3a_num_audio_tokens(const q3a_engine* e, int64_t n_frames);
+/* AsrInference::build_prompt (src/inference.rs:215-257). Writes 15 + num_audio_tokens + n_prefix ids;
+ * `ids` may be NULL to query the length (returned through *len). */
+int32_t q3a_build_prompt(int32_t num_audio_tokens, const int32_t* lang_prefix_ids, int32_t n_prefix,
+                         int32_t* ids, int32_t* len);
+
+/* ---- stage API (device state chains from one stage to the next) -------------------------------------- */
+
+/* WhisperFeatureExtractor::extract (src/mel.rs:49-96) for B utterances.
+ * pcm16k: host f32, utterances concatenated; n_samples[B].  mel_out (nullable): host f32, per
+ * utterance a (num_mel_bins, F_b) row-major block, concatenated.  n_frames_out (nullable): [B]. */
+int32_t q3a_mel(q3a_engine* e, const float* pcm16k, const int64_t* n_samples, int32_t B, float* mel_out,
+                int32_t* n_frames_out);
+
+/* AudioEncoder::forward (src/audio_encoder.rs:79-169) on the mel of the last q3a_mel call.
+ * audio_embeds_out (nullable): host f32 [sum T_b][enc_output_dim].  T_out (nullable): [B]. */
+int32_t q3a_encode(q3a_engine* e, float* audio_embeds_out, int32_t* T_out);
+
+/* Steps 5-7 of AsrInference::transcribe (src/inference.rs:110-149): embed `ids`, overwrite the
+ * <|audio_pad|> rows with the encoder output of the last q3a_encode, RoPE tables, causal prefill.
+ * ids: concatenated prompts, lens[B].  last_logits_out (nullable): host f32 [B][vocab] (last row
+ * only; the reference computes all rows and keeps the last, src/inference.rs:156).
+ * next_ids (nullable): [B] greedy argmax (first-index tie-break). */
+int32_t q3a_prefill(q3a_engine* e, const int32_t* ids, const int32_t* lens, int32_t B, float* last_logits_out,
+                    int32_t* next_ids);
+
+/* One iteration of the greedy loop (src/inference.rs:160-200) for all B sequences: feeds the
+ * previous argmax (or the ids set by q3a_set_next_tokens), returns the new argmax.
+ * done[b]=1 once sequence b has produced an EOS {151643,151645} (the reference breaks out of its
+ * loop there, src/inference.rs:163-165).  logits_out nullable host f32 [B][vocab]. */
+int32_t q3a_decode_step(q3a_engine* e, int32_t* next_ids, uint8_t* done, float* logits_out);
+
+/* Teacher forcing for parity tests: override the token fed by the next q3a_decode_step. */
+int32_t q3a_set_next_tokens(q3a_engine* e, const int32_t* ids, int32_t B);
+
+/* ---- whole path ---------------------------------------------------------------------------------- */
+
+/* Copy B utterances (host f32 16 kHz, concatenated) into the engine's HBM input buffer. */
+int32_t q3a_upload_pcm(q3a_engine* e, const float* pcm16k, const int64_t* n_samples, int32_t B);
+
+/* Steps 2-8 of AsrInference::transcribe (src/inference.rs:95-200) on the resident batch: mel ->
+ * encoder -> prompt/injection -> prefill -> greedy decode.  lang_prefix_ids (nullable) =
+ * tokenizer.encode("language {Lang}") when the language is forced (src/inference.rs:246-251).
+ * fixed_new_tokens > 0: run exactly that many decode iterations ignoring EOS (throughput mode);
+ * 0: stop every sequence at its first EOS, capped by max_new (<= opts.max_new_tokens). */
+int32_t q3a_run_resident(q3a_engine* e, const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new,
+                         int32_t fixed_new_tokens);
+
+/* Generated ids of the last q3a_run_resident: out_ids host [B][stride], out_lens [B] (EOS excluded,
+ * as generated_ids in src/inference.rs:167). */
+int32_t q3a_fetch_ids(q3a_engine* e, int32_t* out_ids, int32_t stride, int32_t* out_lens);
+
+/* upload + run + fetch. */
+int32_t q3a_transcribe_batch(q3a_engine* e, const float* pcm16k, const int64_t* n_samples, int32_t B,
+                             const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new,
+                             int32_t fixed_new_tokens, int32_t* out_ids, int32_t stride, int32_t* out_lens);
+
+/* ---- measurement ---------------------------------------------------------------------------------- */
+
+typedef struct q3a_timings {
+  float mel_ms, encoder_ms, prefill_ms, decode_ms, total_ms; /* hipEvent times of the last q3a_run_resident */
+  int32_t decode_steps, batch, total_audio_tokens, total_prompt_tokens;
+} q3a_timings;
+int32_t q3a_stage_timings(const q3a_engine* e, q3a_timings* out);
+
+/* Per-kernel-class timing of ONE decode step, each launch bracketed by hipEvents on the engine's
+ * stream (eager, not graph).  Requires a batch in decode state (after q3a_run_resident/q3a_prefill).
+ * class ids: see Q3A_KC_* ; arrays have Q3A_KC_COUNT entries. */
+enum { Q3A_KC_GEMV = 0, Q3A_KC_DECODE_ATTN = 1, Q3A_KC_ARGMAX = 2, Q3A_KC_GEMM = 3, Q3A_KC_NORM = 4,
+       Q3A_KC_OTHER = 5, Q3A_KC_COUNT = 6 };
+typedef struct q3a_kernel_profile {
+  float total_us[Q3A_KC_COUNT];
+  int32_t launches[Q3A_KC_COUNT];
+  double weight_bytes[Q3A_KC_COUNT]; /* algorithmic weight bytes streamed by the class in the step */
+} q3a_kernel_profile;
+int32_t q3a_profile_decode_step(q3a_engine* e, q3a_kernel_profile* out);
+
+/* Debug taps (opts.debug_taps=1): copy a named intermediate to host. `bytes` = capacity of dst;
+ * *actual receives the tap size. Names: mel conv1 conv2 conv3 enc_in enc_layer0 enc_last
+ * audio_embeds dec_embed dec_layer0 dec_last_hidden logits. */
+int32_t q3a_debug_read(q3a_engine* e, const char* name, void* dst, uint64_t bytes, uint64_t* actual);
+
+/* Kernel self-tests against naive device references (no model needed): returns max abs error. */
+int32_t q3a_selftest_gemm(int32_t device, int32_t M, int32_t N, int32_t K, int32_t split, float* max_abs_err,
+                          float* ref_abs_max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Q3ASR_H */

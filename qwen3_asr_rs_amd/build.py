@@ -1,0 +1,79 @@
+"""Build libq3asr_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m qwen3_asr_rs_amd.build [--force]
+
+Objects go to build/q3asr/ (git-ignored); the shared library to qwen3_asr_rs_amd/lib/ so it travels
+with the repo snapshot to the GPU box.  A source-hash stamp makes rebuilds incremental.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ_DIR = os.path.join(ROOT, "build", "q3asr")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libq3asr_hip.so")
+
+SOURCES = ["engine.cpp", "model.cpp", "k_gemm.hip", "k_mel.hip", "k_conv1.hip", "k_norm.hip", "k_attn.hip", "k_decode.hip"]
+HEADERS = ["dev.h", "kernels.h", "model.h", "json.h", os.path.join("..", "..", "include", "q3asr.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def _hash(paths) -> str:
+    h = hashlib.sha1()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src: str, hdr_hash: str, force: bool) -> str:
+    spath = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ_DIR, src + ".o")
+    stamp = obj + ".stamp"
+    want = _hash([spath]) + hdr_hash
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
+        return obj
+    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", spath, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hdr_hash = _hash([os.path.join(CSRC, h) for h in HEADERS])
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, hdr_hash, force), SOURCES))
+    link_stamp = LIB_PATH + ".stamp"
+    want = _hash(objs)
+    if force or not os.path.exists(LIB_PATH) or not os.path.exists(link_stamp) or open(link_stamp).read() != want:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        with open(link_stamp, "w") as f:
+            f.write(want)
+        if verbose:
+            print(f"[q3asr build] linked {LIB_PATH}")
+    elif verbose:
+        print(f"[q3asr build] up to date: {LIB_PATH}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,55 @@
+// Device-side helpers shared by the gfx950 kernels (wave = 64 lanes everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace q3a {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;  // MFMA 16x16x32 bf16 A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // MFMA 32x32 accumulator
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t v) { return __uint_as_float(v << 16); }
+// round-to-nearest-even (inputs are finite activations)
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+}
+// two bf16 packed in one dword -> two floats
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// erf-form GELU (reference: Tensor::gelu -> gelu("none"), src/tensor.rs:350-352)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// SiLU (reference: Tensor::silu, src/tensor.rs:354-356)
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+// KV-cache element types: bf16 (default) or f32 (precise mode)
+template <typename T> struct KvIo;
+template <> struct KvIo<float> {
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <> struct KvIo<uint16_t> {
+  static __device__ __forceinline__ float load(const uint16_t* p) { return bf16_bits_to_f32(*p); }
+  static __device__ __forceinline__ void store(uint16_t* p, float v) { *p = (uint16_t)f32_to_bf16_bits(v); }
+  static __device__ __forceinline__ float round(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+};
+
+}  // namespace q3a

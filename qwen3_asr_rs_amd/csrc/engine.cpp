@@ -1,0 +1,1041 @@
+// Engine: owns the weight arena, the workspace and the HIP stream of one GPU and sequences the
+// kernels of the hot path.  Exposes the C ABI of include/q3asr.h.
+//
+// Pipeline per batch of B independent utterances (reference: AsrInference::transcribe,
+// src/inference.rs:89-200, run B times):
+//   pcm -> k_mel -> k_conv1 -> conv2/conv3 (implicit GEMM) -> conv_out GEMM (+pos-emb, valid-token gather)
+//       -> encoder layers {LN, QKV GEMM, window attention, out GEMM+res, LN, fc1 GEMM+GELU, fc2 GEMM+res}
+//       -> ln_post, proj1+GELU, proj2 -> audio embeds -> scattered into the prompt embeddings
+//       -> decoder prefill layers {RMSNorm, QKV GEMM, qk-norm+RoPE+KV append, causal GQA attention,
+//          o GEMM+res, RMSNorm, gate/up GEMM+SiLU*up, down GEMM+res} -> last-row lm_head -> argmax
+//       -> decode steps (GEMV path for <= 4 sequences, GEMM path above), replayed from a hipGraph.
+// All activations between kernels are fp32 in HBM (round 1); weights bf16; KV cache bf16 (fp32 in precise mode).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/q3asr.h"
+#include "kernels.h"
+#include "model.h"
+
+using namespace q3a;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+#define HIPCHK(expr)                                                                                    \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess)                                                                               \
+      fail(std::string("HIP error: ") + hipGetErrorString(_e) + " at " + __FILE__ + ":" + std::to_string(__LINE__) + " (" #expr ")"); \
+  } while (0)
+#define KCHK(expr)                                  \
+  do {                                              \
+    const char* _m = (expr);                        \
+    if (_m) fail(std::string("kernel launch: ") + _m); \
+  } while (0)
+
+constexpr int kAudioPad = 151676, kEos0 = 151643, kEos1 = 151645;  // src/tokenizer.rs:52-59
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool grew = false;
+  void ensure(size_t bytes) {
+    if (bytes <= cap) return;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = (bytes + 255) & ~size_t(255);
+    HIPCHK(hipMalloc(&p, want));
+    cap = want;
+    grew = true;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+template <typename T>
+void upload(DevBuf& b, const std::vector<T>& v, hipStream_t s) {
+  b.ensure(std::max<size_t>(v.size() * sizeof(T), 16));
+  if (!v.empty()) HIPCHK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+}
+
+struct ProfEvent {
+  int kclass;
+  double bytes;
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct q3a_engine {
+  Dims d;
+  ArenaLayout L;
+  q3a_opts opts{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint8_t* arena = nullptr;
+  bool own_arena = false;
+  uint32_t arena_flags = 0;
+  std::string err;
+
+  // constant tables
+  DevBuf dft, filt_t, pos_emb, rope_cos, rope_sin;
+  int rope_positions = 0;
+
+  // ---- batch description (host) ----
+  int B = 0;
+  std::vector<int64_t> n_samples, pcm_off, mel_off;
+  std::vector<int> n_frames, n_chunks, T, tok_off;   // per utterance; tok_off = first encoder token
+  int total_chunks = 0, total_T = 0, max_frames = 0;
+  bool have_mel = false, have_enc = false, have_prefill = false;
+  std::vector<int> P, seq_off;  // prompt lengths / first row
+  int total_P = 0, max_ctx = 0, max_new = 0;
+  std::vector<AttnSeg> enc_segs_h;
+  int enc_max_seg = 0;
+
+  // ---- device workspace ----
+  DevBuf pcm, d_pcm_off, d_n_samples, d_mel_off, d_n_frames, mel, gmax, d_chunk_utt, d_chunk_frame0;
+  DevBuf conv1, conv2, conv3, conv3_rowmap, convout_rowmap;
+  DevBuf enc_x, enc_ln, enc_qkv, enc_ctx, enc_ffn, enc_segs, audio_embeds;
+  DevBuf ids, audio_rowmap, row_seq, row_pos, dec_segs, last_rows;
+  DevBuf dec_x, dec_ln, dec_qkv, dec_ctx, dec_act, kcache, vcache;
+  DevBuf x_dec, d_pos, next_tok, out_ids, step_count, done, s_ln, s_qkv, s_ctx, s_act, logits, forced_tok;
+  size_t kv_layer_elems = 0;
+
+  // ---- graph ----
+  hipGraphExec_t graph_exec = nullptr;
+  std::string graph_sig;
+
+  // ---- measurement ----
+  q3a_timings timings{};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::vector<ProfEvent>* prof = nullptr;
+  std::map<std::string, DevBuf> taps;
+  std::map<std::string, size_t> tap_bytes;
+
+  bool precise() const { return opts.precise != 0; }
+  bool kv_f32() const { return opts.precise != 0; }
+  size_t kv_elem() const { return kv_f32() ? 4 : 2; }
+  template <typename T> const T* w(uint64_t off) const { return reinterpret_cast<const T*>(arena + off); }
+  const float* wf(uint64_t off) const { return w<float>(off); }
+  const uint16_t* wh(uint64_t off) const { return w<uint16_t>(off); }
+
+  void tap(const char* name, const void* ptr, size_t bytes) {
+    if (!opts.debug_taps || bytes == 0) return;
+    DevBuf& t = taps[name];
+    t.ensure(bytes);
+    tap_bytes[name] = bytes;
+    HIPCHK(hipMemcpyAsync(t.p, ptr, bytes, hipMemcpyDeviceToDevice, stream));
+  }
+
+  // run fn() (which enqueues exactly one kernel class) optionally bracketed by events
+  template <class F> void timed(int kclass, double bytes, F&& fn) {
+    if (!prof) {
+      fn();
+      return;
+    }
+    ProfEvent pe{kclass, bytes, nullptr, nullptr};
+    HIPCHK(hipEventCreate(&pe.a));
+    HIPCHK(hipEventCreate(&pe.b));
+    HIPCHK(hipEventRecord(pe.a, stream));
+    fn();
+    HIPCHK(hipEventRecord(pe.b, stream));
+    prof->push_back(pe);
+  }
+
+  // =====================================================================================
+  void init_common(const std::string& model_dir, int dev, const q3a_opts* o) {
+    if (o) opts = *o; else q3a_opts_default(&opts);
+    if (opts.max_new_tokens <= 0) opts.max_new_tokens = 4096;
+    d = parse_config_file(model_dir + "/config.json");
+    validate_dims(d);
+    L = plan_arena(d);
+    device = dev;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev == 0)
+      fail("no HIP device available: libq3asr_hip has no CPU fallback (hipGetDeviceCount: " + std::string(hipGetErrorString(e)) + ")");
+    if (dev < 0 || dev >= n_dev) fail("device index out of range");
+    HIPCHK(hipSetDevice(dev));
+    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+  }
+
+  void init_tables() {
+    auto dftm = make_dft_matrix(400, 416);
+    auto filt = make_mel_filterbank_T(d.n_mels, 400, 16000, 202);
+    auto pe = make_sinusoid_rows(d.tokens_per_chunk(), d.enc_d);
+    upload(dft, dftm, stream);
+    upload(filt_t, filt, stream);
+    upload(pos_emb, pe, stream);
+    ensure_rope(8192);
+    HIPCHK(hipStreamSynchronize(stream));
+  }
+
+  void ensure_rope(int n_pos) {
+    if (n_pos <= rope_positions) return;
+    int n = std::max(n_pos, 8192);
+    std::vector<float> c, s;
+    make_rope_tables(n, d.head_dim, d.rope_theta, c, s);
+    HIPCHK(hipStreamSynchronize(stream));
+    upload(rope_cos, c, stream);
+    upload(rope_sin, s, stream);
+    HIPCHK(hipStreamSynchronize(stream));
+    rope_positions = n;
+  }
+
+  void check_arena_header() {
+    ArenaHeader h;
+    HIPCHK(hipMemcpy(&h, arena, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.magic != kArenaMagic || h.version != kArenaVersion) fail("weight arena: bad magic/version");
+    if (h.total_bytes != L.total) fail("weight arena: size does not match config.json");
+    arena_flags = h.flags;
+  }
+
+  // =====================================================================================
+  // batch geometry (host integers; audio_encoder.rs:79-121, 263-279)
+  void set_batch(const int64_t* ns, int b) {
+    if (b <= 0) fail("batch must be >= 1");
+    B = b;
+    n_samples.assign(ns, ns + b);
+    pcm_off.resize(b); mel_off.resize(b); n_frames.resize(b); n_chunks.resize(b); T.resize(b); tok_off.resize(b);
+    std::vector<int> chunk_utt, chunk_frame0, convout_map, conv3_map;
+    enc_segs_h.clear();
+    int64_t po = 0, mo = 0;
+    int tok = 0;
+    total_chunks = 0; max_frames = 0; enc_max_seg = 0;
+    const int cf = d.chunk_frames(), tpc = d.tokens_per_chunk(), cpw = d.chunks_per_window();
+    for (int u = 0; u < b; ++u) {
+      if (ns[u] < 161) fail("utterance too short: reflection padding needs more than 160 samples (src/mel.rs:63-65)");
+      pcm_off[u] = po;
+      po += (ns[u] + 3) & ~int64_t(3);
+      int F = (int)((ns[u] + 159) / 160);  // mel.rs:51,83-84
+      n_frames[u] = F;
+      max_frames = std::max(max_frames, F);
+      mel_off[u] = mo;
+      mo += (int64_t)F * d.n_mels;
+      int nc = (F + cf - 1) / cf;
+      n_chunks[u] = nc;
+      tok_off[u] = tok;
+      std::vector<int> valid(nc);
+      for (int c = 0; c < nc; ++c) {
+        int frames = std::min(cf, F - c * cf);
+        valid[c] = Dims::feat_len(frames);
+        chunk_utt.push_back(u);
+        chunk_frame0.push_back(c * cf);
+        for (int t = 0; t < tpc; ++t) convout_map.push_back(t < valid[c] ? tok + t : -1);
+        tok += valid[c];
+      }
+      T[u] = tok - tok_off[u];
+      // attention windows (audio_encoder.rs:172-260): None (= one segment) when nc <= cpw
+      int t0 = tok_off[u];
+      if (nc <= cpw) {
+        enc_segs_h.push_back(AttnSeg{t0, T[u], (int64_t)t0 * 3 * d.enc_d});
+        enc_max_seg = std::max(enc_max_seg, T[u]);
+      } else {
+        for (int c0 = 0; c0 < nc; c0 += cpw) {
+          int len = 0;
+          for (int c = c0; c < std::min(nc, c0 + cpw); ++c) len += valid[c];
+          enc_segs_h.push_back(AttnSeg{t0, len, (int64_t)t0 * 3 * d.enc_d});
+          enc_max_seg = std::max(enc_max_seg, len);
+          t0 += len;
+        }
+      }
+      total_chunks += nc;
+    }
+    total_T = tok;
+    if (enc_max_seg > 128 && false) fail("attention window too long");
+    const int f3 = d.freq3();
+    conv3_map.resize((size_t)total_chunks * f3 * tpc);
+    for (int c = 0; c < total_chunks; ++c)
+      for (int f = 0; f < f3; ++f)
+        for (int t = 0; t < tpc; ++t) conv3_map[((size_t)c * f3 + f) * tpc + t] = (c * tpc + t) * f3 + f;
+    pcm.ensure((size_t)po * 4);
+    upload(d_pcm_off, pcm_off, stream);
+    upload(d_n_samples, n_samples, stream);
+    upload(d_mel_off, mel_off, stream);
+    upload(d_n_frames, n_frames, stream);
+    upload(d_chunk_utt, chunk_utt, stream);
+    upload(d_chunk_frame0, chunk_frame0, stream);
+    upload(convout_rowmap, convout_map, stream);
+    upload(conv3_rowmap, conv3_map, stream);
+    upload(enc_segs, enc_segs_h, stream);
+    mel.ensure((size_t)mo * 4);
+    gmax.ensure((size_t)b * 4);
+    HIPCHK(hipStreamSynchronize(stream));  // host vectors above go out of scope
+    have_mel = have_enc = have_prefill = false;
+  }
+
+  void upload_pcm(const float* host, const int64_t* ns, int b) {
+    set_batch(ns, b);
+    int64_t src = 0;
+    for (int u = 0; u < b; ++u) {
+      HIPCHK(hipMemcpyAsync(pcm.as<float>() + pcm_off[u], host + src, (size_t)ns[u] * 4, hipMemcpyHostToDevice, stream));
+      src += ns[u];
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+  }
+
+  // =====================================================================================
+  void run_mel() {
+    MelBatch mb{pcm.as<float>(), d_pcm_off.as<int64_t>(), d_n_samples.as<int64_t>(), d_mel_off.as<int64_t>(),
+                d_n_frames.as<int>(), mel.as<float>(), gmax.as<unsigned>()};
+    KCHK(launch_mel(mb, B, max_frames, dft.as<float>(), filt_t.as<float>(), stream));
+    have_mel = true;
+    size_t bytes = 0;
+    for (int u = 0; u < B; ++u) bytes += (size_t)n_frames[u] * d.n_mels * 4;
+    tap("mel", mel.p, bytes);
+  }
+
+  // =====================================================================================
+  void run_encoder() {
+    if (!have_mel) fail("q3a_encode: no mel (call q3a_mel first)");
+    const int C = d.conv_ch, D = d.enc_d, Fn = d.enc_ffn;
+    const int H1 = Dims::conv_len(d.n_mels), W1 = Dims::conv_len(d.chunk_frames());
+    const int H2 = Dims::conv_len(H1), W2 = Dims::conv_len(W1);
+    const int H3 = Dims::conv_len(H2), W3 = Dims::conv_len(W2);
+    const bool sp = precise();
+    const size_t nch = (size_t)total_chunks;
+    conv1.ensure(nch * H1 * W1 * C * 4);
+    conv2.ensure(nch * H2 * W2 * C * 4);
+    conv3.ensure(nch * H3 * W3 * C * 4);
+    const size_t Tt = (size_t)total_T;
+    enc_x.ensure(Tt * D * 4); enc_ln.ensure(Tt * D * 4); enc_qkv.ensure(Tt * 3 * D * 4); enc_ctx.ensure(Tt * D * 4);
+    enc_ffn.ensure(Tt * Fn * 4); audio_embeds.ensure(Tt * d.enc_out * 4);
+
+    ChunkTable ct{d_chunk_utt.as<int>(), d_chunk_frame0.as<int>()};
+    KCHK(launch_conv1(mel.as<float>(), d_mel_off.as<int64_t>(), d_n_frames.as<int>(), ct, total_chunks, d.n_mels,
+                      d.chunk_frames(), wf(L.conv1_w), wf(L.conv1_b), C, conv1.as<float>(), stream));
+    tap("conv1", conv1.p, nch * H1 * W1 * C * 4);
+    {
+      GemmEpilogue ep;
+      ep.out = conv2.as<float>(); ep.ldo = C; ep.bias = wf(L.conv2_b); ep.act = 1;
+      KCHK(launch_conv3x3s2_gemm(conv1.as<float>(), total_chunks, H1, W1, C, wh(L.conv2_w), C, ep, sp, stream));
+      tap("conv2", conv2.p, nch * H2 * W2 * C * 4);
+    }
+    {
+      GemmEpilogue ep;  // rows land as [chunk][t][f][c]  (audio_encoder.rs:132-133 permute fused away)
+      ep.out = conv3.as<float>(); ep.ldo = C; ep.bias = wf(L.conv3_b); ep.act = 1; ep.rowmap = conv3_rowmap.as<int>();
+      KCHK(launch_conv3x3s2_gemm(conv2.as<float>(), total_chunks, H2, W2, C, wh(L.conv3_w), C, ep, sp, stream));
+      tap("conv3", conv3.p, nch * H3 * W3 * C * 4);
+    }
+    {
+      GemmEpilogue ep;  // conv_out + positional embedding (restarting per chunk) + valid-token gather
+      ep.out = enc_x.as<float>(); ep.ldo = D;
+      ep.bias = (arena_flags & kFlagConvOutBias) ? wf(L.conv_out_b) : nullptr;
+      ep.rowmap = convout_rowmap.as<int>();
+      ep.addend = pos_emb.as<float>(); ep.addend_period = W3;
+      KCHK(launch_gemm(conv3.as<float>(), H3 * C, wh(L.conv_out_w), total_chunks * W3, D, H3 * C, ep, false, sp, stream));
+      tap("enc_in", enc_x.p, Tt * D * 4);
+    }
+    AttnArgs at{};
+    at.q = enc_qkv.as<float>(); at.q_rs = 3 * D;
+    at.k = enc_qkv.as<float>() + D; at.v = enc_qkv.as<float>() + 2 * D; at.kv_hs = 64; at.kv_rs = 3 * D;
+    at.o = enc_ctx.as<float>(); at.o_rs = D;
+    at.segs = enc_segs.as<AttnSeg>(); at.n_segs = (int)enc_segs_h.size(); at.max_len = enc_max_seg;
+    at.n_kv_heads = d.enc_heads; at.scale_div = 8.0f;  // sqrt(64), layers.rs:161
+    for (int li = 0; li < d.enc_layers; ++li) {
+      const EncLayerOff& e = L.enc[li];
+      KCHK(launch_layernorm(enc_x.as<float>(), wf(e.ln1_w), wf(e.ln1_b), enc_ln.as<float>(), total_T, D, 1e-5f, stream));
+      {
+        GemmEpilogue ep; ep.out = enc_qkv.as<float>(); ep.ldo = 3 * D; ep.bias = wf(e.qkv_b);
+        KCHK(launch_gemm(enc_ln.as<float>(), D, wh(e.qkv_w), total_T, 3 * D, D, ep, false, sp, stream));
+      }
+      KCHK(launch_attn_enc(at, stream));
+      {
+        GemmEpilogue ep; ep.out = enc_x.as<float>(); ep.ldo = D; ep.bias = wf(e.out_b); ep.resid = enc_x.as<float>();
+        KCHK(launch_gemm(enc_ctx.as<float>(), D, wh(e.out_w), total_T, D, D, ep, false, sp, stream));
+      }
+      KCHK(launch_layernorm(enc_x.as<float>(), wf(e.ln2_w), wf(e.ln2_b), enc_ln.as<float>(), total_T, D, 1e-5f, stream));
+      {
+        GemmEpilogue ep; ep.out = enc_ffn.as<float>(); ep.ldo = Fn; ep.bias = wf(e.fc1_b); ep.act = 1;
+        KCHK(launch_gemm(enc_ln.as<float>(), D, wh(e.fc1_w), total_T, Fn, D, ep, false, sp, stream));
+      }
+      {
+        GemmEpilogue ep; ep.out = enc_x.as<float>(); ep.ldo = D; ep.bias = wf(e.fc2_b); ep.resid = enc_x.as<float>();
+        KCHK(launch_gemm(enc_ffn.as<float>(), Fn, wh(e.fc2_w), total_T, D, Fn, ep, false, sp, stream));
+      }
+      if (li == 0) tap("enc_layer0", enc_x.p, Tt * D * 4);
+    }
+    tap("enc_last", enc_x.p, Tt * D * 4);
+    KCHK(launch_layernorm(enc_x.as<float>(), wf(L.ln_post_w), wf(L.ln_post_b), enc_ln.as<float>(), total_T, D, 1e-5f, stream));
+    {
+      GemmEpilogue ep; ep.out = enc_ctx.as<float>(); ep.ldo = D; ep.bias = wf(L.proj1_b); ep.act = 1;
+      KCHK(launch_gemm(enc_ln.as<float>(), D, wh(L.proj1_w), total_T, D, D, ep, false, sp, stream));
+    }
+    {
+      GemmEpilogue ep; ep.out = audio_embeds.as<float>(); ep.ldo = d.enc_out; ep.bias = wf(L.proj2_b);
+      KCHK(launch_gemm(enc_ctx.as<float>(), D, wh(L.proj2_w), total_T, d.enc_out, D, ep, false, sp, stream));
+    }
+    tap("audio_embeds", audio_embeds.p, Tt * d.enc_out * 4);
+    HIPCHK(hipGetLastError());
+    have_enc = true;
+  }
+
+  // =====================================================================================
+  // prompts: ids concatenated, lens[B]  (inference.rs:104-137)
+  void setup_prompts(const int32_t* ids_h, const int32_t* lens, int b, int max_new_req) {
+    if (!have_enc) fail("q3a_prefill: no encoder output (call q3a_encode first)");
+    if (b != B) fail("q3a_prefill: batch size differs from the encoded batch");
+    P.assign(lens, lens + b);
+    seq_off.resize(b);
+    std::vector<int> rowseq, rowpos, amap((size_t)total_T, -1), last(b);
+    int off = 0, maxP = 0;
+    for (int s = 0; s < b; ++s) {
+      seq_off[s] = off;
+      int na = 0;
+      for (int i = 0; i < P[s]; ++i) {
+        rowseq.push_back(s);
+        rowpos.push_back(i);
+        int id = ids_h[off + i];
+        if (id < 0 || id >= d.vocab) fail("q3a_prefill: token id out of range");
+        if (id == kAudioPad) {
+          if (na >= T[s]) fail("q3a_prefill: more <|audio_pad|> tokens than encoder tokens");
+          amap[(size_t)tok_off[s] + na] = off + i;
+          ++na;
+        }
+      }
+      if (na != T[s]) fail("q3a_prefill: number of <|audio_pad|> tokens does not match the encoder output length");
+      if (P[s] <= 0) fail("q3a_prefill: empty prompt");
+      last[s] = off + P[s] - 1;
+      off += P[s];
+      maxP = std::max(maxP, P[s]);
+    }
+    total_P = off;
+    max_new = std::min(std::max(max_new_req, 1), opts.max_new_tokens);
+    max_ctx = ((maxP + max_new + 1 + 63) / 64) * 64;
+    ensure_rope(max_ctx);
+    std::vector<int> ids_v(ids_h, ids_h + total_P);
+    std::vector<AttnSeg> segs(b);
+    for (int s = 0; s < b; ++s)
+      segs[s] = AttnSeg{seq_off[s], P[s], (int64_t)s * d.n_kv * max_ctx * 128};
+    upload(ids, ids_v, stream);
+    upload(row_seq, rowseq, stream);
+    upload(row_pos, rowpos, stream);
+    upload(audio_rowmap, amap, stream);
+    upload(last_rows, last, stream);
+    upload(dec_segs, segs, stream);
+    upload(d_pos, P, stream);
+    const size_t Pt = (size_t)total_P, H = d.hidden;
+    dec_x.ensure(Pt * H * 4); dec_ln.ensure(Pt * H * 4); dec_qkv.ensure(Pt * d.qkv_dim() * 4);
+    dec_ctx.ensure(Pt * d.q_dim() * 4); dec_act.ensure(Pt * d.inter * 4);
+    kv_layer_elems = (size_t)b * d.n_kv * max_ctx * 128;
+    kcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
+    vcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
+    x_dec.ensure((size_t)b * H * 4); next_tok.ensure((size_t)b * 4); forced_tok.ensure((size_t)b * 4);
+    out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
+    s_ln.ensure((size_t)b * H * 4); s_qkv.ensure((size_t)b * d.qkv_dim() * 4); s_ctx.ensure((size_t)b * d.q_dim() * 4);
+    s_act.ensure((size_t)b * d.inter * 4); logits.ensure((size_t)b * d.vocab * 4);
+    HIPCHK(hipMemsetAsync(step_count.p, 0, (size_t)b * 4, stream));
+    HIPCHK(hipMemsetAsync(done.p, 0, (size_t)b, stream));
+    HIPCHK(hipMemsetAsync(out_ids.p, 0, (size_t)b * max_new * 4, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+  }
+
+  void* kc_layer(int l) { return (uint8_t*)kcache.p + (size_t)l * kv_layer_elems * kv_elem(); }
+  void* vc_layer(int l) { return (uint8_t*)vcache.p + (size_t)l * kv_layer_elems * kv_elem(); }
+
+  // final norm + lm_head on x_dec -> logits, then argmax/finalize
+  void run_head(int advance) {
+    const int S = B, H = d.hidden, V = d.vocab;
+    const double wbytes = 2.0 * V * H;
+    if (S <= 4) {
+      GemvArgs g{};
+      g.x = x_dec.as<float>(); g.ldx = H; g.rms_w = wf(L.final_norm); g.eps = d.rms_eps;
+      g.W = wh(L.lm_head); g.N = V; g.K = H; g.mode = 0; g.out = logits.as<float>(); g.ldo = V;
+      timed(Q3A_KC_GEMV, wbytes, [&] { KCHK(launch_gemv(g, S, stream)); });
+    } else {
+      timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(L.final_norm), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
+      GemmEpilogue ep; ep.out = logits.as<float>(); ep.ldo = V;
+      timed(Q3A_KC_GEMM, wbytes, [&] { KCHK(launch_gemm(s_ln.as<float>(), H, wh(L.lm_head), S, V, H, ep, false, precise(), stream)); });
+    }
+    FinalizeArgs f{};
+    f.logits = logits.as<float>(); f.V = V; f.next_tok = next_tok.as<int>(); f.out_ids = out_ids.as<int>();
+    f.out_stride = max_new; f.step_count = step_count.as<int>(); f.pos = d_pos.as<int>(); f.advance = advance;
+    f.done = done.as<uint8_t>(); f.embed = wh(L.embed); f.H = H; f.x_next = x_dec.as<float>(); f.eos0 = kEos0; f.eos1 = kEos1;
+    timed(Q3A_KC_ARGMAX, 0, [&] { KCHK(launch_argmax_finalize(f, S, stream)); });
+  }
+
+  void run_prefill() {
+    const int H = d.hidden, I = d.inter, QD = d.q_dim(), QKV = d.qkv_dim();
+    const bool sp = precise();
+    KCHK(launch_embed(ids.as<int>(), total_P, wh(L.embed), H, kAudioPad, dec_x.as<float>(), stream));
+    // audio injection (inference.rs:114-124): one row scatter instead of T full-tensor slice_scatter copies
+    scatter_audio_rows();
+    tap("dec_embed", dec_x.p, (size_t)total_P * H * 4);
+    AttnArgs at{};
+    at.q = dec_qkv.as<float>(); at.q_rs = QKV; at.kv_hs = (int64_t)max_ctx * 128; at.kv_rs = 128;
+    at.o = dec_ctx.as<float>(); at.o_rs = QD; at.segs = dec_segs.as<AttnSeg>(); at.n_segs = B;
+    at.max_len = *std::max_element(P.begin(), P.end()); at.n_kv_heads = d.n_kv;
+    at.scale_div = sqrtf((float)d.head_dim);  // layers.rs:327-328
+    const bool qkv_bias = arena_flags & kFlagDecQkvBias, o_bias = arena_flags & kFlagDecOBias, mlp_bias = arena_flags & kFlagDecMlpBias;
+    for (int li = 0; li < d.dec_layers; ++li) {
+      const DecLayerOff& l = L.dec[li];
+      KCHK(launch_rmsnorm(dec_x.as<float>(), wf(l.in_ln), dec_ln.as<float>(), total_P, H, d.rms_eps, stream));
+      {
+        GemmEpilogue ep; ep.out = dec_qkv.as<float>(); ep.ldo = QKV; ep.bias = qkv_bias ? wf(l.qkv_b) : nullptr;
+        KCHK(launch_gemm(dec_ln.as<float>(), H, wh(l.qkv_w), total_P, QKV, H, ep, false, sp, stream));
+      }
+      RopeKvArgs rk{};
+      rk.qkv = dec_qkv.as<float>(); rk.row_seq = row_seq.as<int>(); rk.row_pos = row_pos.as<int>();
+      rk.q_norm = wf(l.q_norm); rk.k_norm = wf(l.k_norm); rk.eps = d.rms_eps;
+      rk.cos_t = rope_cos.as<float>(); rk.sin_t = rope_sin.as<float>();
+      rk.kcache = kc_layer(li); rk.vcache = vc_layer(li); rk.n_q = d.n_q; rk.n_kv = d.n_kv; rk.max_ctx = max_ctx;
+      KCHK(launch_qknorm_rope_kv(rk, total_P, kv_f32(), stream));
+      at.k = kc_layer(li); at.v = vc_layer(li);
+      KCHK(launch_attn_prefill(at, d.n_q / d.n_kv, kv_f32(), stream));
+      {
+        GemmEpilogue ep; ep.out = dec_x.as<float>(); ep.ldo = H; ep.resid = dec_x.as<float>(); ep.bias = o_bias ? wf(l.o_b) : nullptr;
+        KCHK(launch_gemm(dec_ctx.as<float>(), QD, wh(l.o_w), total_P, H, QD, ep, false, sp, stream));
+      }
+      KCHK(launch_rmsnorm(dec_x.as<float>(), wf(l.post_ln), dec_ln.as<float>(), total_P, H, d.rms_eps, stream));
+      {
+        GemmEpilogue ep; ep.out = dec_act.as<float>(); ep.ldo = I; ep.bias = mlp_bias ? wf(l.gu_b) : nullptr;
+        KCHK(launch_gemm(dec_ln.as<float>(), H, wh(l.gu_w), total_P, 2 * I, H, ep, true, sp, stream));
+      }
+      {
+        GemmEpilogue ep; ep.out = dec_x.as<float>(); ep.ldo = H; ep.resid = dec_x.as<float>(); ep.bias = mlp_bias ? wf(l.down_b) : nullptr;
+        KCHK(launch_gemm(dec_act.as<float>(), I, wh(l.down_w), total_P, H, I, ep, false, sp, stream));
+      }
+      if (li == 0) tap("dec_layer0", dec_x.p, (size_t)total_P * H * 4);
+    }
+    // only the last row of every sequence feeds the lm_head (the reference computes all rows and keeps
+    // the last, text_decoder.rs:111-112 + inference.rs:156)
+    KCHK(launch_gather_rows(dec_x.as<float>(), last_rows.as<int>(), B, H, x_dec.as<float>(), stream));
+    tap("dec_last_hidden", x_dec.p, (size_t)B * H * 4);
+    run_head(0);
+    tap("logits", logits.p, (size_t)B * d.vocab * 4);
+    HIPCHK(hipGetLastError());
+    have_prefill = true;
+  }
+
+  void scatter_audio_rows();
+
+  // one greedy-loop iteration for all sequences (inference.rs:160-200)
+  void enqueue_decode_step() {
+    const int S = B, H = d.hidden, I = d.inter, QD = d.q_dim(), QKV = d.qkv_dim();
+    const bool qkv_bias = arena_flags & kFlagDecQkvBias, o_bias = arena_flags & kFlagDecOBias, mlp_bias = arena_flags & kFlagDecMlpBias;
+    const bool gemv = S <= 4;
+    DecodeAttnArgs da{};
+    da.qkv = s_qkv.as<float>(); da.pos = d_pos.as<int>(); da.eps = d.rms_eps;
+    da.cos_t = rope_cos.as<float>(); da.sin_t = rope_sin.as<float>(); da.out = s_ctx.as<float>();
+    da.n_q = d.n_q; da.n_kv = d.n_kv; da.max_ctx = max_ctx; da.scale_div = sqrtf((float)d.head_dim);
+    for (int li = 0; li < d.dec_layers; ++li) {
+      const DecLayerOff& l = L.dec[li];
+      if (gemv) {
+        GemvArgs g{};
+        g.x = x_dec.as<float>(); g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
+        g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = s_qkv.as<float>(); g.ldo = QKV;
+        timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, stream)); });
+      } else {
+        timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(l.in_ln), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
+        GemmEpilogue ep; ep.out = s_qkv.as<float>(); ep.ldo = QKV; ep.bias = qkv_bias ? wf(l.qkv_b) : nullptr;
+        timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { KCHK(launch_gemm(s_ln.as<float>(), H, wh(l.qkv_w), S, QKV, H, ep, false, precise(), stream)); });
+      }
+      da.q_norm = wf(l.q_norm); da.k_norm = wf(l.k_norm); da.kcache = kc_layer(li); da.vcache = vc_layer(li);
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), stream)); });
+      if (gemv) {
+        GemvArgs g{};
+        g.x = s_ctx.as<float>(); g.ldx = QD; g.W = wh(l.o_w); g.N = H; g.K = QD; g.bias = o_bias ? wf(l.o_b) : nullptr;
+        g.mode = 1; g.out = x_dec.as<float>(); g.ldo = H; g.resid = x_dec.as<float>();
+        timed(Q3A_KC_GEMV, 2.0 * H * QD, [&] { KCHK(launch_gemv(g, S, stream)); });
+        GemvArgs u{};
+        u.x = x_dec.as<float>(); u.ldx = H; u.rms_w = wf(l.post_ln); u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
+        u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act.as<float>(); u.ldo = I;
+        timed(Q3A_KC_GEMV, 4.0 * I * H, [&] { KCHK(launch_gemv(u, S, stream)); });
+        GemvArgs dn{};
+        dn.x = s_act.as<float>(); dn.ldx = I; dn.W = wh(l.down_w); dn.N = H; dn.K = I; dn.bias = mlp_bias ? wf(l.down_b) : nullptr;
+        dn.mode = 1; dn.out = x_dec.as<float>(); dn.ldo = H; dn.resid = x_dec.as<float>();
+        timed(Q3A_KC_GEMV, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, stream)); });
+      } else {
+        const bool sp = precise();
+        {
+          GemmEpilogue ep; ep.out = x_dec.as<float>(); ep.ldo = H; ep.resid = x_dec.as<float>(); ep.bias = o_bias ? wf(l.o_b) : nullptr;
+          timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { KCHK(launch_gemm(s_ctx.as<float>(), QD, wh(l.o_w), S, H, QD, ep, false, sp, stream)); });
+        }
+        timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(l.post_ln), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
+        {
+          GemmEpilogue ep; ep.out = s_act.as<float>(); ep.ldo = I; ep.bias = mlp_bias ? wf(l.gu_b) : nullptr;
+          timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_gemm(s_ln.as<float>(), H, wh(l.gu_w), S, 2 * I, H, ep, true, sp, stream)); });
+        }
+        {
+          GemmEpilogue ep; ep.out = x_dec.as<float>(); ep.ldo = H; ep.resid = x_dec.as<float>(); ep.bias = mlp_bias ? wf(l.down_b) : nullptr;
+          timed(Q3A_KC_GEMM, 2.0 * H * I, [&] { KCHK(launch_gemm(s_act.as<float>(), I, wh(l.down_w), S, H, I, ep, false, sp, stream)); });
+        }
+      }
+    }
+    run_head(1);
+  }
+
+  std::string make_graph_sig() const {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%d/%d/%d/%p/%p/%p/%p/%p/%p/%p", B, max_ctx, max_new, kcache.p, vcache.p, x_dec.p,
+             logits.p, s_qkv.p, out_ids.p, rope_cos.p);
+    return buf;
+  }
+
+  void decode_steps(int n) {
+    if (!have_prefill) fail("decode: no prefill state");
+    if (n <= 0) return;
+    if (!opts.use_graph || prof) {
+      for (int i = 0; i < n; ++i) enqueue_decode_step();
+      HIPCHK(hipGetLastError());
+      return;
+    }
+    std::string sig = make_graph_sig();
+    if (!graph_exec || sig != graph_sig) {
+      if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+      hipGraph_t g = nullptr;
+      HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      try {
+        enqueue_decode_step();
+      } catch (...) {
+        hipGraph_t tmp = nullptr;
+        (void)hipStreamEndCapture(stream, &tmp);
+        if (tmp) (void)hipGraphDestroy(tmp);
+        throw;
+      }
+      HIPCHK(hipStreamEndCapture(stream, &g));
+      HIPCHK(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+      graph_sig = sig;
+    }
+    for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(graph_exec, stream));
+  }
+
+  // steps 2-8 on the resident batch
+  void run_resident(const int32_t* lang_ids, int n_prefix, int max_new_req, int fixed_new) {
+    if (B <= 0) fail("q3a_run_resident: no batch uploaded");
+    if (fixed_new > 0) max_new_req = fixed_new;
+    if (max_new_req <= 0) max_new_req = opts.max_new_tokens;
+    HIPCHK(hipEventRecord(ev[0], stream));
+    run_mel();
+    HIPCHK(hipEventRecord(ev[1], stream));
+    run_encoder();
+    HIPCHK(hipEventRecord(ev[2], stream));
+    std::vector<int32_t> ids_v, lens(B);
+    for (int s = 0; s < B; ++s) {
+      int32_t len = 0;
+      q3a_build_prompt(T[s], lang_ids, n_prefix, nullptr, &len);
+      size_t o = ids_v.size();
+      ids_v.resize(o + len);
+      q3a_build_prompt(T[s], lang_ids, n_prefix, ids_v.data() + o, &len);
+      lens[s] = len;
+    }
+    setup_prompts(ids_v.data(), lens.data(), B, max_new_req);
+    run_prefill();
+    HIPCHK(hipEventRecord(ev[3], stream));
+    // the prefill already produced token 0; every decode step feeds one token and yields the next
+    int steps = 0;
+    if (fixed_new > 0) {
+      steps = fixed_new - 1;
+      decode_steps(steps);
+    } else {
+      const int chunk = 8;
+      std::vector<uint8_t> dn(B);
+      while (steps < max_new - 1) {
+        HIPCHK(hipMemcpyAsync(dn.data(), done.p, B, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        bool all = true;
+        for (int s = 0; s < B; ++s) all = all && dn[s];
+        if (all) break;
+        int n = std::min(chunk, max_new - 1 - steps);
+        decode_steps(n);
+        steps += n;
+      }
+    }
+    HIPCHK(hipEventRecord(ev[4], stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipGetLastError());
+    float ms;
+    HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[1])); timings.mel_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, ev[1], ev[2])); timings.encoder_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, ev[2], ev[3])); timings.prefill_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, ev[3], ev[4])); timings.decode_ms = ms;
+    HIPCHK(hipEventElapsedTime(&ms, ev[0], ev[4])); timings.total_ms = ms;
+    timings.decode_steps = steps; timings.batch = B; timings.total_audio_tokens = total_T; timings.total_prompt_tokens = total_P;
+  }
+
+  void fetch_ids(int32_t* out, int stride, int32_t* out_lens) {
+    if (!have_prefill) fail("q3a_fetch_ids: nothing generated");
+    std::vector<int> all((size_t)B * max_new), sc(B);
+    HIPCHK(hipMemcpy(all.data(), out_ids.p, all.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sc.data(), step_count.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+    for (int s = 0; s < B; ++s) {
+      int n = std::min(sc[s], max_new), len = 0;
+      for (; len < n; ++len) {
+        int t = all[(size_t)s * max_new + len];
+        if (!fixed_mode_ && (t == kEos0 || t == kEos1)) break;  // generated_ids excludes EOS (inference.rs:163-167)
+      }
+      out_lens[s] = len;
+      for (int i = 0; i < std::min(len, stride); ++i) out[(size_t)s * stride + i] = all[(size_t)s * max_new + i];
+    }
+  }
+  bool fixed_mode_ = false;
+
+  ~q3a_engine() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    DevBuf* bufs[] = {&dft, &filt_t, &pos_emb, &rope_cos, &rope_sin, &pcm, &d_pcm_off, &d_n_samples, &d_mel_off, &d_n_frames,
+                      &mel, &gmax, &d_chunk_utt, &d_chunk_frame0, &conv1, &conv2, &conv3, &conv3_rowmap, &convout_rowmap,
+                      &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
+                      &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
+                      &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok};
+    for (auto* b : bufs) b->release();
+    for (auto& kv : taps) kv.second.release();
+    if (own_arena && arena) (void)hipFree(arena);
+    for (auto& x : ev)
+      if (x) (void)hipEventDestroy(x);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+// audio rows: dec_x[audio_rowmap[t]] = audio_embeds[t]
+void q3a_engine::scatter_audio_rows() {
+  KCHK(launch_scatter_rows(audio_embeds.as<float>(), audio_rowmap.as<int>(), total_T, d.hidden, dec_x.as<float>(), stream));
+}
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+#define Q3A_TRY(e) try {
+#define Q3A_CATCH(e)                                 \
+  }                                                  \
+  catch (const std::exception& ex) {                 \
+    if (e) (e)->err = ex.what();                     \
+    g_last_error = ex.what();                        \
+    return 1;                                        \
+  }                                                  \
+  catch (...) {                                      \
+    if (e) (e)->err = "unknown error";               \
+    g_last_error = "unknown error";                  \
+    return 1;                                        \
+  }                                                  \
+  return 0;
+
+extern "C" {
+
+void q3a_opts_default(q3a_opts* o) {
+  memset(o, 0, sizeof(*o));
+  o->precise = 0;
+  o->max_new_tokens = 4096;
+  o->use_graph = 1;
+  o->debug_taps = 0;
+}
+
+static int32_t create_impl(const char* model_dir, int32_t device, void* dev_arena, uint64_t bytes, const q3a_opts* opts,
+                           q3a_engine** out) {
+  q3a_engine* e = nullptr;
+  try {
+    if (!model_dir || !out) fail("null argument");
+    e = new q3a_engine();
+    e->init_common(model_dir, device, opts);
+    if (dev_arena) {
+      if (bytes != e->L.total) fail("q3a_engine_create_from_arena: arena size does not match config.json");
+      e->arena = (uint8_t*)dev_arena;
+      e->own_arena = false;
+    } else {
+      Checkpoint ck(model_dir);
+      std::vector<uint8_t> host(e->L.total);
+      pack_arena(e->d, e->L, ck, host.data());
+      HIPCHK(hipMalloc((void**)&e->arena, e->L.total));
+      e->own_arena = true;
+      HIPCHK(hipMemcpy(e->arena, host.data(), e->L.total, hipMemcpyHostToDevice));
+    }
+    e->check_arena_header();
+    e->init_tables();
+    *out = e;
+    return 0;
+  } catch (const std::exception& ex) {
+    g_last_error = ex.what();
+    delete e;
+    if (out) *out = nullptr;
+    return 1;
+  }
+}
+
+int32_t q3a_engine_create(const char* model_dir, int32_t device, const q3a_opts* opts, q3a_engine** out) {
+  return create_impl(model_dir, device, nullptr, 0, opts, out);
+}
+int32_t q3a_engine_create_from_arena(const char* model_dir, int32_t device, void* device_arena, uint64_t bytes,
+                                     const q3a_opts* opts, q3a_engine** out) {
+  if (!device_arena) { g_last_error = "null arena"; return 1; }
+  return create_impl(model_dir, device, device_arena, bytes, opts, out);
+}
+
+int32_t q3a_arena_bytes(const char* model_dir, uint64_t* bytes) {
+  q3a_engine* e = nullptr;
+  Q3A_TRY(e)
+  Dims d = parse_config_file(std::string(model_dir) + "/config.json");
+  validate_dims(d);
+  *bytes = plan_arena(d).total;
+  Q3A_CATCH(e)
+}
+int32_t q3a_arena_pack(const char* model_dir, void* host_dst, uint64_t bytes) {
+  q3a_engine* e = nullptr;
+  Q3A_TRY(e)
+  Dims d = parse_config_file(std::string(model_dir) + "/config.json");
+  validate_dims(d);
+  ArenaLayout L = plan_arena(d);
+  if (bytes != L.total) fail("q3a_arena_pack: buffer size does not match q3a_arena_bytes");
+  Checkpoint ck(model_dir);
+  pack_arena(d, L, ck, (uint8_t*)host_dst);
+  Q3A_CATCH(e)
+}
+
+void q3a_engine_destroy(q3a_engine* e) { delete e; }
+const char* q3a_last_error(const q3a_engine* e) { return e ? e->err.c_str() : g_last_error.c_str(); }
+
+int32_t q3a_get_dims(const q3a_engine* e, q3a_dims* o) {
+  if (!e || !o) return 1;
+  const Dims& d = e->d;
+  memset(o, 0, sizeof(*o));
+  o->enc_d_model = d.enc_d; o->enc_layers = d.enc_layers; o->enc_heads = d.enc_heads; o->enc_ffn = d.enc_ffn;
+  o->num_mel_bins = d.n_mels; o->n_window = d.n_window; o->n_window_infer = d.n_window_infer; o->conv_channels = d.conv_ch;
+  o->enc_output_dim = d.enc_out; o->max_source_positions = d.max_source_positions;
+  o->vocab_size = d.vocab; o->hidden_size = d.hidden; o->intermediate_size = d.inter; o->dec_layers = d.dec_layers;
+  o->num_q_heads = d.n_q; o->num_kv_heads = d.n_kv; o->head_dim = d.head_dim; o->tie_word_embeddings = d.tie_embeddings;
+  o->mrope_interleaved = d.mrope_interleaved;
+  for (size_t i = 0; i < 4 && i < d.mrope_section.size(); ++i) o->mrope_section[i] = d.mrope_section[i];
+  o->rms_norm_eps = d.rms_eps; o->rope_theta = d.rope_theta;
+  return 0;
+}
+
+int64_t q3a_num_frames(int64_t n_samples) { return (n_samples + 159) / 160; }
+int32_t q3a_num_audio_tokens(const q3a_engine* e, int64_t n_frames) { return e ? e->d.audio_tokens(n_frames) : -1; }
+
+int32_t q3a_build_prompt(int32_t num_audio_tokens, const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t* ids,
+                         int32_t* len) {
+  // inference.rs:215-257
+  static const int32_t head[9] = {151644, 8948, 198, 151645, 198, 151644, 872, 198, 151669};
+  static const int32_t tail[6] = {151670, 151645, 198, 151644, 77091, 198};
+  if (!lang_prefix_ids) n_prefix = 0;
+  int32_t n = 9 + num_audio_tokens + 6 + n_prefix;
+  if (len) *len = n;
+  if (!ids) return 0;
+  int32_t* p = ids;
+  for (int i = 0; i < 9; ++i) *p++ = head[i];
+  for (int i = 0; i < num_audio_tokens; ++i) *p++ = kAudioPad;
+  for (int i = 0; i < 6; ++i) *p++ = tail[i];
+  for (int i = 0; i < n_prefix; ++i) *p++ = lang_prefix_ids[i];
+  return 0;
+}
+
+int32_t q3a_upload_pcm(q3a_engine* e, const float* pcm16k, const int64_t* n_samples, int32_t B) {
+  if (!e) return 1;
+  Q3A_TRY(e)
+  HIPCHK(hipSetDevice(e->device));
+  e->upload_pcm(pcm16k, n_samples, B);
+  Q3A_CATCH(e)
+}
+
+int32_t q3a_mel(q3a_engine* e, const float* pcm16k, const int64_t* n_samples, int32_t B, float* mel_out,
+                int32_t* n_frames_out) {
+  if (!e) return 1;
+  Q3A_TRY(e)
+  HIPCHK(hipSetDevice(e->device));
+  e->upload_pcm(pcm16k, n_samples, B);
+  e->run_mel();
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipGetLastError());
+  if (n_frames_out)
+    for (int u = 0; u < B; ++u) n_frames_out[u] = e->n_frames[u];
+  if (mel_out) {
+    size_t total = 0;
+    for (int u = 0; u < B; ++u) total += (size_t)e->n_frames[u] * e->d.n_mels;
+    HIPCHK(hipMemcpy(mel_out, e->mel.p, total * 4, hipMemcpyDeviceToHost));
+  }
+  Q3A_CATCH(e)
+}
+
+int32_t q3a_encode(q3a_engine* e, float* audio_embeds_out, int32_t* T_out) {
+  if (!e) return 1;
+  Q3A_TRY(e)
+  HIPCHK(hipSetDevice(e->device));
+  e->run_encoder();
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipGetLastError());
+  if (T_out)
+    for (int u = 0; u < e->B; ++u) T_out[u] = e->T[u];
+  if (audio_embeds_out)
+    HIPCHK(hipMemcpy(audio_embeds_out, e->audio_embeds.p, (size_t)e->total_T * e->d.enc_out * 4, hipMemcpyDeviceToHost));
+  Q3A_CATCH(e)
+}
+
+int32_t q3a_prefill(q3a_engine* e, const int32_t* ids, const int32_t* lens, int32_t B, float* last_logits_out,
+                    int32_t* next_ids) {
+  if (!e) return 1;
+  Q3A_TRY(e)
+  HIPCHK(hipSetDevice(e->device));
+  e->fixed_mode_ = false;
+  e->setup_prompts(ids, lens, B, e->opts.max_new_tokens);
+  e->run_prefill();
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipGetLastError());
+  if (last_logits_out) HIPCHK(hipMemcpy(last_logits_out, e->logits.p, (size_t)B * e->d.vocab * 4, hipMemcpyDeviceToHost));
+  if (next_ids) HIPCHK(hipMemcpy(next_ids, e->next_tok.p, (size_t)B * 4, hipMemcpyDeviceToHost));
+  Q3A_CATCH(e)
+}
+
+int32_t q3a_decode_step(q3a_engine* e, int32_t* next_ids, uint8_t* done, float* logits_out) {
+  if (!e) return 1;
+  Q3A_TRY(e)
+  HIPCHK(hipSetDevice(e->device));
+  {
+    // capacity guard: position of the token being fed must stay inside the cache
+    std::vector<int> pos(e->B);
+    HIPCHK(hipMemcpy(pos.data(), e->d_pos.p, (size_t)e->B * 4, hipMemcpyDeviceToHost));
+    for (int s = 0; s < e->B; ++s)
+      if (pos[s] + 1 > e->max_ctx) fail("q3a_decode_step: KV cache capacity exhausted (max_new_tokens reached)");
+  }
+  e->decode_steps(1);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipGetLastError());
+  if (next_ids) HIPCHK(hipMemcpy(next_ids, e->next_tok.p, (size_t)e->B * 4, hipMemcpyDeviceToHost));
+  if (done) HIPCHK(hipMemcpy(done, e->done.p, (size_t)e->B, hipMemcpyDeviceToHost));
+  if (logits_out) HIPCHK(hipMemcpy(logits_out, e->logits.p, (size_t)e->B * e->d.vocab * 4, hipMemcpyDeviceToHost));
+  Q3A_CATCH(e)
+}
+
+int32_t q3a_set_next_tokens(q3a_engine* e, const int32_t* ids, int32_t B) {
+  if (!e) return 1;
+  Q3A_TRY(e)
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->have_prefill || B != e->B) fail("q3a_set_next_tokens: no decode state / batch mismatch");
+  for (int s = 0; s < B; ++s)
+    if (ids[s] < 0 || ids[s] >= e->d.vocab) fail("q3a_set_next_tokens: token id out of range");
+  HIPCHK(hipMemcpy(e->forced_tok.p, ids, (size_t)B * 4, hipMemcpyHostToDevice));
+  KCHK(launch_set_tokens(e->forced_tok.as<int>(), B, e->wh(e->L.embed), e->d.hidden, e->x_dec.as<float>(),
+                         e->next_tok.as<int>(), e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  Q3A_CATCH(e)
+}
+
+int32_t q3a_run_resident(q3a_engine* e, const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new,
+                         int32_t fixed_new_tokens) {
+  if (!e) return 1;
+  Q3A_TRY(e)
+  HIPCHK(hipSetDevice(e->device));
+  e->fixed_mode_ = fixed_new_tokens > 0;
+  e->run_resident(lang_prefix_ids, n_prefix, max_new, fixed_new_tokens);
+  Q3A_CATCH(e)
+}
+
+int32_t q3a_fetch_ids(q3a_engine* e, int32_t* out_ids, int32_t stride, int32_t* out_lens) {
+  if (!e) return 1;
+  Q3A_TRY(e)
+  HIPCHK(hipSetDevice(e->device));
+  e->fetch_ids(out_ids, stride, out_lens);
+  Q3A_CATCH(e)
+}
+
+int32_t q3a_transcribe_batch(q3a_engine* e, const float* pcm16k, const int64_t* n_samples, int32_t B,
+                             const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new, int32_t fixed_new_tokens,
+                             int32_t* out_ids, int32_t stride, int32_t* out_lens) {
+  if (!e) return 1;
+  Q3A_TRY(e)
+  HIPCHK(hipSetDevice(e->device));
+  e->upload_pcm(pcm16k, n_samples, B);
+  e->fixed_mode_ = fixed_new_tokens > 0;
+  e->run_resident(lang_prefix_ids, n_prefix, max_new, fixed_new_tokens);
+  e->fetch_ids(out_ids, stride, out_lens);
+  Q3A_CATCH(e)
+}
+
+int32_t q3a_stage_timings(const q3a_engine* e, q3a_timings* out) {
+  if (!e || !out) return 1;
+  *out = e->timings;
+  return 0;
+}
+
+int32_t q3a_profile_decode_step(q3a_engine* e, q3a_kernel_profile* out) {
+  if (!e || !out) return 1;
+  Q3A_TRY(e)
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->have_prefill) fail("q3a_profile_decode_step: no decode state");
+  std::vector<ProfEvent> evs;
+  e->prof = &evs;
+  try {
+    e->enqueue_decode_step();
+    HIPCHK(hipStreamSynchronize(e->stream));
+  } catch (...) {
+    e->prof = nullptr;
+    throw;
+  }
+  e->prof = nullptr;
+  memset(out, 0, sizeof(*out));
+  for (auto& pe : evs) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, pe.a, pe.b));
+    out->total_us[pe.kclass] += ms * 1000.f;
+    out->launches[pe.kclass] += 1;
+    out->weight_bytes[pe.kclass] += pe.bytes;
+    (void)hipEventDestroy(pe.a);
+    (void)hipEventDestroy(pe.b);
+  }
+  Q3A_CATCH(e)
+}
+
+int32_t q3a_debug_read(q3a_engine* e, const char* name, void* dst, uint64_t bytes, uint64_t* actual) {
+  if (!e) return 1;
+  Q3A_TRY(e)
+  HIPCHK(hipSetDevice(e->device));
+  auto it = e->taps.find(name);
+  if (it == e->taps.end()) fail(std::string("q3a_debug_read: no tap named '") + name + "' (opts.debug_taps set?)");
+  size_t n = e->tap_bytes[name];
+  if (actual) *actual = n;
+  if (dst) {
+    if (bytes < n) fail("q3a_debug_read: destination too small");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(dst, it->second.p, n, hipMemcpyDeviceToHost));
+  }
+  Q3A_CATCH(e)
+}
+
+int32_t q3a_selftest_gemm(int32_t device, int32_t M, int32_t N, int32_t K, int32_t split, float* max_abs_err,
+                          float* ref_abs_max) {
+  q3a_engine* e = nullptr;
+  Q3A_TRY(e)
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) fail("no HIP device available");
+  HIPCHK(hipSetDevice(device));
+  std::vector<float> X((size_t)M * K);
+  std::vector<uint16_t> W((size_t)N * K);
+  uint32_t st = 12345u;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
+  for (auto& v : X) v = rnd();
+  for (auto& v : W) { float f = rnd(); uint32_t u; memcpy(&u, &f, 4); v = (uint16_t)(u >> 16); }  // truncation is fine for a test
+  DevBuf dX, dW, dY, dR;
+  dX.ensure(X.size() * 4); dW.ensure(W.size() * 2); dY.ensure((size_t)M * N * 4); dR.ensure((size_t)M * N * 4);
+  HIPCHK(hipMemcpy(dX.p, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dW.p, W.data(), W.size() * 2, hipMemcpyHostToDevice));
+  GemmEpilogue ep; ep.out = dY.as<float>(); ep.ldo = N;
+  KCHK(launch_gemm(dX.as<float>(), K, dW.as<uint16_t>(), M, N, K, ep, false, split != 0, nullptr));
+  launch_gemm_ref(dX.as<float>(), dW.as<uint16_t>(), dR.as<float>(), M, N, K, nullptr);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipGetLastError());
+  std::vector<float> Y((size_t)M * N), R((size_t)M * N);
+  HIPCHK(hipMemcpy(Y.data(), dY.p, Y.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(R.data(), dR.p, R.size() * 4, hipMemcpyDeviceToHost));
+  float me = 0.f, rm = 0.f;
+  for (size_t i = 0; i < Y.size(); ++i) { me = std::max(me, std::fabs(Y[i] - R[i])); rm = std::max(rm, std::fabs(R[i])); }
+  if (max_abs_err) *max_abs_err = me;
+  if (ref_abs_max) *ref_abs_max = rm;
+  dX.release(); dW.release(); dY.release(); dR.release();
+  Q3A_CATCH(e)
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// First conv of the audio stem (C_in = 1): 3x3, stride 2, pad 1, + bias + erf-GELU
+// (src/audio_encoder.rs:127, Conv2d::forward src/layers.rs:109-118).  Memory/VALU bound (9 MACs per
+// output) -- no MFMA.  Fuses the chunking of src/audio_encoder.rs:96-124: the kernel reads the
+// utterance's (128, F) mel block directly, chunk c covers frames [c*100, c*100+100) and everything
+// past the utterance's last frame reads as zero (the reference zero-pads the tail chunk).
+// Output is NHWC fp32 [chunk][H/2][W/2][Cout] so that conv2's implicit-GEMM rows are contiguous.
+#include "dev.h"
+#include "kernels.h"
+
+namespace q3a {
+namespace {
+
+constexpr int MAX_W = 128;     // chunk_frames <= 128
+constexpr int MAX_COUT = 512;  // weights + bias staged in LDS
+
+__global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ mel, const int64_t* __restrict__ mel_off,
+                                                    const int* __restrict__ n_frames, ChunkTable ct, int n_mels,
+                                                    int chunk_frames, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, int Cout, float* __restrict__ out) {
+  __shared__ float in_l[3][MAX_W + 2];     // three input rows, column index shifted by +1 (pad)
+  __shared__ float w_l[MAX_COUT * 9];
+  __shared__ float b_l[MAX_COUT];
+  const int chunk = blockIdx.y, oh = blockIdx.x;
+  const int OH = (n_mels - 1) / 2 + 1, OW = (chunk_frames - 1) / 2 + 1;
+  const int utt = ct.chunk_utt[chunk], fr0 = ct.chunk_frame0[chunk];
+  const int F = n_frames[utt];
+  const float* m = mel + mel_off[utt];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 3 * (MAX_W + 2); i += 256) {
+    const int kh = i / (MAX_W + 2), col = i % (MAX_W + 2);
+    const int ih = oh * 2 - 1 + kh, iw = col - 1;
+    float v = 0.f;
+    if (ih >= 0 && ih < n_mels && iw >= 0 && iw < chunk_frames && fr0 + iw < F) v = m[(size_t)ih * F + fr0 + iw];
+    in_l[kh][col] = v;
+  }
+  for (int i = tid; i < Cout * 9; i += 256) w_l[i] = w[i];
+  for (int i = tid; i < Cout; i += 256) b_l[i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  float* o = out + ((size_t)chunk * OH + oh) * OW * Cout;
+  const int total = OW * Cout;
+  for (int e = tid; e < total; e += 256) {
+    const int ow = e / Cout, co = e - ow * Cout;
+    const float* wp = w_l + co * 9;
+    float acc = b_l[co];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) acc += wp[kh * 3 + kw] * in_l[kh][ow * 2 + kw];  // (ow*2-1+kw)+1
+    o[e] = gelu_erf(acc);
+  }
+}
+
+}  // namespace
+
+const char* launch_conv1(const float* mel, const int64_t* mel_off, const int* n_frames, const ChunkTable& ct,
+                         int n_chunks, int n_mels, int chunk_frames, const float* w, const float* b, int Cout,
+                         float* out, hipStream_t s) {
+  if (n_chunks <= 0) return nullptr;
+  if (chunk_frames > MAX_W) return "conv1: chunk_frames > 128 unsupported";
+  if (Cout > MAX_COUT) return "conv1: more than 512 channels unsupported";
+  const int OH = (n_mels - 1) / 2 + 1;
+  hipLaunchKernelGGL(conv1_kernel, dim3(OH, n_chunks), dim3(256), 0, s, mel, mel_off, n_frames, ct, n_mels,
+                     chunk_frames, w, b, Cout, out);
+  return nullptr;
+}
+
+}  // namespace q3a

@@ -1,0 +1,139 @@
+// Launch wrappers of the gfx950 kernels.  Every launch goes to the caller's HIP stream; nothing here
+// allocates or synchronises (graph-capture safe).  A non-null return value is a static error string.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace q3a {
+
+// ---- GEMM (k_gemm.hip) -----------------------------------------------------------------------------
+struct GemmEpilogue {
+  float* out = nullptr;          // [rows][ldo] fp32
+  int ldo = 0;
+  const float* bias = nullptr;   // [N] or null
+  int act = 0;                   // 0 none, 1 erf-GELU
+  const float* resid = nullptr;  // [rows][ldo] added after the activation (may alias out)
+  const int* rowmap = nullptr;   // GEMM row m -> output row (negative: drop the row); null = identity
+  const float* addend = nullptr; // [addend_period][ldo] added before the activation (positional embedding)
+  int addend_period = 1;
+};
+// Y = X[M][K](fp32, row stride lda) . W[N][K]^T(bf16).  glu: W rows are [16 gate|16 up] blocks, out has N/2 columns.
+const char* launch_gemm(const float* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
+                        bool glu, bool split, hipStream_t s);
+// 3x3 / stride 2 / pad 1 convolution as implicit GEMM over an NHWC fp32 map [imgs][H][W][C]; W bf16 [Cout][3][3][C].
+const char* launch_conv3x3s2_gemm(const float* X, int imgs, int H, int Wd, int C, const uint16_t* Wt, int Cout,
+                                  const GemmEpilogue& ep, bool split, hipStream_t s);
+void launch_gemm_ref(const float* X, const uint16_t* W, float* Y, int M, int N, int K, hipStream_t s);
+
+// ---- log-mel front end (k_mel.hip) -------------------------------------------------------------------
+struct MelBatch {
+  const float* pcm;            // concatenated utterances
+  const int64_t* pcm_off;      // [B] sample offset of each utterance (device)
+  const int64_t* n_samples;    // [B] (device)
+  const int64_t* mel_off;      // [B] float offset of each (128, F_b) block (device)
+  const int* n_frames;         // [B] (device)
+  float* mel;                  // output, concatenated (128, F_b) blocks
+  unsigned* gmax_key;          // [B] order-preserving key of the per-utterance max (zeroed by the launcher)
+};
+const char* launch_mel(const MelBatch& mb, int B, int max_frames, const float* dft /*[400][416]*/,
+                       const float* filt_t /*[202][128]*/, hipStream_t s);
+
+// ---- conv stem first layer (k_conv1.hip) ---------------------------------------------------------------
+struct ChunkTable {
+  const int* chunk_utt;    // [C] utterance of each chunk (device)
+  const int* chunk_frame0; // [C] first mel frame of the chunk inside its utterance (device)
+};
+// mel (128, F_b) blocks -> NHWC fp32 [chunk][64][W/2][Cout] = gelu(conv3x3 s2 p1 + bias), chunk zero-padded to `chunk_frames`
+const char* launch_conv1(const float* mel, const int64_t* mel_off, const int* n_frames, const ChunkTable& ct,
+                         int n_chunks, int n_mels, int chunk_frames, const float* w /*[Cout][9]*/,
+                         const float* b, int Cout, float* out, hipStream_t s);
+
+// ---- norms (k_norm.hip) ----------------------------------------------------------------------------------
+const char* launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps,
+                             hipStream_t s);
+const char* launch_rmsnorm(const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s);
+
+// ---- attention over independent segments (k_attn.hip) ------------------------------------------------------
+// One segment = a set of `len` queries/keys that attend to each other (encoder windows, non-causal) or a
+// whole decoder sequence (causal).  Element (row j, head h, dim d):
+//   Q: q + (q_row0 + j) * q_rs + h * HD + d                          (fp32)
+//   K: k + kv_off + kvh * kv_hs + j * kv_rs + d   (V likewise)       (KVT = float or bf16)
+//   O: o + (q_row0 + j) * o_rs + h * HD + d                          (fp32)
+struct AttnSeg {
+  int q_row0;
+  int len;
+  int64_t kv_off;
+};
+struct AttnArgs {
+  const float* q; int q_rs;
+  const void* k; const void* v; int64_t kv_hs; int kv_rs;
+  float* o; int o_rs;
+  const AttnSeg* segs; int n_segs; int max_len;
+  int n_kv_heads;
+  float scale_div;  // scores are divided by this (sqrt(head_dim)), as the reference does
+};
+const char* launch_attn_enc(const AttnArgs& a, hipStream_t s);                            // HD=64, 1 q-head per kv head, non-causal, fp32 K/V
+const char* launch_attn_prefill(const AttnArgs& a, int group, bool kv_f32, hipStream_t s);  // HD=128, causal, GQA group 1/2/4
+
+// ---- decoder glue (k_decode.hip) ----------------------------------------------------------------------------
+// hidden[r] = embed[ids[r]] for rows whose id is not `skip_id` (audio rows are written by the encoder tail)
+const char* launch_embed(const int* ids, int rows, const uint16_t* embed, int H, int skip_id, float* out, hipStream_t s);
+struct RopeKvArgs {
+  float* qkv;               // [rows][qkv_dim] fp32; q part is normalised + rotated in place
+  const int* row_seq;       // [rows] sequence of the row
+  const int* row_pos;       // [rows] position inside the sequence
+  const float* q_norm; const float* k_norm; float eps;
+  const float* cos_t; const float* sin_t;  // [max_pos][64]
+  void* kcache; void* vcache;              // this layer: [S][n_kv][max_ctx][128]
+  int n_q, n_kv, max_ctx;
+};
+const char* launch_qknorm_rope_kv(const RopeKvArgs& a, int rows, bool kv_f32, hipStream_t s);
+// dst[i] = src[row_idx[i]]
+const char* launch_gather_rows(const float* src, const int* row_idx, int n, int D, float* dst, hipStream_t s);
+// dst[dst_row[i]] = src[i]  (negative dst_row: skip)
+const char* launch_scatter_rows(const float* src, const int* dst_row, int n, int D, float* dst, hipStream_t s);
+
+// GEMV family: y[b][n] = sum_k xn[b][k] * W[n][k], b < NB <= 4, x fp32 staged in LDS, W bf16 streamed once.
+struct GemvArgs {
+  const float* x; int ldx;      // [NB][K]
+  const float* rms_w;           // non-null: x is RMS-normalised with this weight first (eps below)
+  float eps;
+  const uint16_t* W; int N; int K;
+  const float* bias;            // [N] or null
+  int mode;                     // 0: store, 1: out = resid + y, 2: GLU (W rows in [16 gate|16 up] blocks; N = 2*inter)
+  float* out; int ldo;
+  const float* resid;
+};
+const char* launch_gemv(const GemvArgs& a, int NB, hipStream_t s);
+
+struct DecodeAttnArgs {
+  const float* qkv;            // [S][qkv_dim] fp32 (raw projections of the current token)
+  const int* pos;              // [S] number of tokens already in the cache = position of the current token
+  const float* q_norm; const float* k_norm; float eps;
+  const float* cos_t; const float* sin_t;
+  void* kcache; void* vcache;  // this layer
+  float* out;                  // [S][n_q*128]
+  int n_q, n_kv, max_ctx;
+  float scale_div;
+};
+const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
+
+struct FinalizeArgs {
+  const float* logits;     // [S][V]
+  int V;
+  int* next_tok;           // [S] token to feed next (written)
+  int* out_ids;            // [S][out_stride] generated ids (written at step_count[s])
+  int out_stride;
+  int* step_count;         // [S]
+  int* pos;                // [S] += advance
+  int advance;
+  uint8_t* done;           // [S] sticky: set when the argmax is EOS
+  const uint16_t* embed; int H;
+  float* x_next;           // [S][H] embedding of the chosen token
+  int eos0, eos1;
+};
+const char* launch_argmax_finalize(const FinalizeArgs& a, int S, hipStream_t s);
+// x_next[s] = embed[tok[s]]; next_tok[s] = tok[s]  (teacher forcing)
+const char* launch_set_tokens(const int* tok, int S, const uint16_t* embed, int H, float* x_next, int* next_tok, hipStream_t s);
+
+}  // namespace q3a
