@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""Benchmark of the Qwen3-ASR hot path on MI355X (contract: see the task statement / DESIGN.md section 6).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path (log-mel -> audio encoder -> prefill -> greedy decode) over
+one batch of synthetic 30 s clips that is already resident in HBM.  Default workload = BASELINE.json
+configs[1]: Qwen3-ASR-0.6B, bf16 weights, 1 clip per GPU, 100 new tokens (EOS ignored: the weights are
+synthetic, so natural EOS never fires; 100 tokens / 30 s is the speech-rate the survey fixes).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def cpu_baseline(model_dir: str, clip: np.ndarray, new_tokens: int) -> dict:
+    """The fp32 oracle (a port of the reference's tch-CPU op sequence, inefficiencies included) timed on
+    this box's host cores on a bounded sample: one 30 s clip, front end + prefill + a few decode steps,
+    extrapolated linearly to `new_tokens` steps."""
+    from oracle import q3asr_oracle as O
+    torch.set_grad_enabled(False)
+    orc = O.AsrOracle(model_dir)
+    secs = len(clip) / 16000.0
+    t0 = time.time(); orc.transcribe_ids(clip, fixed_new_tokens=2, keep_logits=False); t2 = time.time() - t0
+    t0 = time.time(); orc.transcribe_ids(clip, fixed_new_tokens=8, keep_logits=False); t8 = time.time() - t0
+    t_dec = max((t8 - t2) / 6.0, 0.0)
+    t_front = max(t2 - 2 * t_dec, 0.0)
+    total = t_front + new_tokens * t_dec
+    return {"value": round(secs / total, 3), "unit": "audio-seconds/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 clip x {secs:.0f}s: mel+encoder+prefill measured once ({t_front:.2f}s), decode "
+                      f"{t_dec*1e3:.1f} ms/token measured over 6 tokens, extrapolated to {new_tokens} tokens"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="clips per GPU")
+    ap.add_argument("--preset", default="0.6b")
+    ap.add_argument("--seconds", type=float, default=30.0)
+    ap.add_argument("--new-tokens", type=int, default=100)
+    ap.add_argument("--precise", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ckpt-dir", default=None)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from qwen3_asr_rs_amd import synthetic
+    from qwen3_asr_rs_amd.engine import HipEngine
+
+    model_dir = args.ckpt_dir or f"/tmp/q3a_ckpt_{args.preset.replace('.', 'p')}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if rank == 0:
+            synthetic.write_checkpoint(model_dir, args.preset, seed=0, shards=2 if args.preset == "1.7b" else 1)
+        dist.barrier()
+        from qwen3_asr_rs_amd.distributed import broadcast_arena
+        arena = broadcast_arena(model_dir, dev, src=0)  # one RCCL broadcast of the weight arena over xGMI
+        torch.cuda.synchronize()
+        eng = HipEngine(model_dir, local_rank, precise=args.precise, max_new_tokens=max(args.new_tokens, 16),
+                        device_arena=(arena.data_ptr(), arena.numel()))
+    else:
+        synthetic.write_checkpoint(model_dir, args.preset, seed=0, shards=2 if args.preset == "1.7b" else 1)
+        eng = HipEngine(model_dir, local_rank, precise=args.precise, max_new_tokens=max(args.new_tokens, 16))
+
+    B = args.batch
+    clips = [synthetic.synthetic_clip(rank * B + i, args.seconds) for i in range(B)]
+    eng.upload_pcm(clips)  # inputs resident in HBM before the timed region
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.run_resident(None, 0, args.new_tokens)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run_resident(None, 0, args.new_tokens)  # synchronises its stream before returning
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stage = eng.timings()
+    prof = eng.profile_decode_step()  # per-launch HIP events on the engine's stream, one eager decode step
+
+    if rank == 0:
+        audio_seconds = world * B * args.seconds * args.steps
+        g = prof["gemv"] if prof["gemv"]["launches"] else prof["gemm"]
+        kname = "gemv_kernel (decode weight streaming)" if prof["gemv"]["launches"] else "gemm_kernel (decode, batched)"
+        bytes_per_launch = g["weight_bytes"] / max(g["launches"], 1)
+        avg_us = g["total_us"] / max(g["launches"], 1)
+        achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+        out = {
+            "metric": "audio-seconds/sec (RTFx) Qwen3-ASR-0.6B greedy, 30s clips" if args.preset == "0.6b"
+                      else f"audio-seconds/sec (RTFx) Qwen3-ASR-{args.preset} greedy, 30s clips",
+            "value": round(audio_seconds / elapsed, 3),
+            "unit": "audio-seconds/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if not args.precise else "bf16x2-split",
+            "data": "synthetic (seeded speech-band noise clips; random-init weights in the reference's safetensors layout)",
+            "config": {"workload": f"Qwen3-ASR-{args.preset} bf16, batch={B} x {args.seconds:.0f}s synthetic 16kHz clip per GPU, "
+                                   f"{args.new_tokens} new tokens (fixed, EOS ignored)",
+                       "clips_per_gpu": B, "clip_seconds": args.seconds, "new_tokens": args.new_tokens,
+                       "parallelism": f"dp{world} (independent utterances per GPU, no data-path collective)"},
+            "stage_ms": {k: round(float(v), 3) for k, v in stage.items() if k.endswith("_ms")},
+            "decode_step_profile_us": {k: round(v["total_us"], 1) for k, v in prof.items() if v["launches"]},
+            "roofline": {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_us, 3),
+                         "launches_per_token": g["launches"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(model_dir, clips[0], args.new_tokens)
+            except Exception as ex:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "error": str(ex)}
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -127,11 +127,13 @@ def _write_safetensors(path: str, tensors: List[Tuple[str, torch.Tensor]]):
 
 
 def write_checkpoint(model_dir: str, preset: str = "tiny", seed: int = 0, shards: int = 1,
-                     cfg: Optional[dict] = None) -> str:
+                     cfg: Optional[dict] = None, eos_trap: bool = False) -> str:
     """Write config.json + model.safetensors (or `shards` shard files + index json, exercising
-    the sharded path of src/weights.rs:29-58).  Idempotent: a finished directory is reused."""
+    the sharded path of src/weights.rs:29-58).  Idempotent: a finished directory is reused.
+    eos_trap (untied lm_head only): column 0 of the lm_head is zeroed except +/-64 on the two EOS rows,
+    so every argmax is an EOS token -- exercises the stop condition of src/inference.rs:163-165."""
     cfg = cfg or PRESETS[preset]
-    tag = hashlib.sha1(json.dumps([cfg, seed, shards], sort_keys=True).encode()).hexdigest()[:12]
+    tag = hashlib.sha1(json.dumps([cfg, seed, shards, eos_trap], sort_keys=True).encode()).hexdigest()[:12]
     done = os.path.join(model_dir, f".complete.{tag}")
     if os.path.exists(done):
         return model_dir
@@ -141,6 +143,13 @@ def write_checkpoint(model_dir: str, preset: str = "tiny", seed: int = 0, shards
     gen = torch.Generator().manual_seed(seed)
     specs = tensor_specs(cfg)
     tensors = [(k, _gen_tensor(shape, kind, scale, gen)) for k, shape, kind, scale in specs]
+    if eos_trap:
+        assert not cfg["text_config"].get("tie_word_embeddings", True), "eos_trap needs an untied lm_head"
+        for k, t in tensors:
+            if k == "thinker.lm_head.weight":
+                t[:, 0] = 0
+                t[151643, 0] = 64.0
+                t[151645, 0] = -64.0
     if shards <= 1:
         _write_safetensors(os.path.join(model_dir, "model.safetensors"), tensors)
     else:

@@ -1,0 +1,201 @@
+"""GPU parity tests (pytest -m gpu): every stage of the HIP path, called through the C ABI, against the
+fp32 oracle on the same seeded inputs.
+
+Tolerances (floating point; measured headroom ~10x):
+  precise mode (bf16 hi+lo split activations, fp32 KV)  rel-L2 <= 1e-4 per stage, logits max-abs <= 2e-4,
+                                                        greedy ids exact
+  default mode (bf16 activations into the MFMA, bf16 KV) rel-L2 <= 2e-2 per stage, logits max-abs <= 6e-2,
+                                                        greedy ids exact wherever the oracle's top-1/top-2
+                                                        margin exceeds twice the observed logit error
+  log-mel (fp32, weight-free, both modes)               max-abs <= 1e-4 vs the oracle
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import q3asr_oracle as O
+from qwen3_asr_rs_amd import synthetic
+from qwen3_asr_rs_amd.audio import load_audio
+from qwen3_asr_rs_amd.engine import HipEngine, selftest_gemm
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = {True: dict(rel=1e-4, logit=2e-4), False: dict(rel=2e-2, logit=6e-2)}
+
+
+def rel_l2(got, ref):
+    got, ref = np.asarray(got, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.isfinite(got).all()
+    return float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 32), (70, 96, 64), (390, 2688, 896), (1000, 480, 4320), (3000, 1024, 3072)])
+@pytest.mark.parametrize("split", [False, True])
+def test_gemm_against_device_reference(shape, split):
+    """MFMA GEMM vs a naive fp64-accumulating kernel on asymmetric random data (transpose-detecting)."""
+    err, ref = selftest_gemm(*shape, split=split)
+    assert err <= (2e-5 if split else 4e-3) * ref, (err, ref)
+
+
+def test_mel_reference_clips_and_hf_golden(tiny_dir):
+    """Weight-free stage: real parity on the reference's own clips, also against the HF fixture."""
+    eng = HipEngine(tiny_dir, 0)
+    fe = O.WhisperFeatureExtractor()
+    g = np.load(os.path.join(GOLDEN, "hf_mel.npz"))
+    clips = [load_audio(os.path.join(GOLDEN, "test_audio", f"sample{i}.wav"), 16000) for i in (1, 2, 3)]
+    clips.append(synthetic.synthetic_clip(7, 30.0))
+    clips.append(synthetic.synthetic_clip(8, 1.003))          # not a multiple of the hop, shorter than one chunk
+    clips.append(np.zeros(4000, dtype=np.float32))            # digital silence: log floor / max-8 clamp path
+    mels = eng.mel(clips)
+    for i, (c, m) in enumerate(zip(clips, mels)):
+        ref = fe.extract(c).numpy()
+        assert m.shape == ref.shape
+        assert np.abs(m - ref).max() <= 1e-4, (i, np.abs(m - ref).max())
+    for i in (1, 2, 3):
+        assert np.abs(mels[i - 1][:, ::4] - g[f"sample{i}_mel_q"]).max() < 5e-3
+    eng.close()
+
+
+def _stage_check(model_dir, clips, precise, steps=4):
+    tol = TOL[precise]
+    orc = O.AsrOracle(model_dir)
+    res = [orc.transcribe_ids(c, fixed_new_tokens=steps, want_taps=True) for c in clips]
+    eng = HipEngine(model_dir, 0, precise=precise, debug_taps=True, max_new_tokens=32)
+    eng.mel(clips)
+    embeds = eng.encode()
+    cat = lambda key, f=(lambda t: t): np.concatenate([f(r.taps[key]).contiguous().numpy().ravel() for r in res])
+    assert rel_l2(eng.debug_read("conv1"), cat("conv1", lambda t: t.permute(0, 2, 3, 1))) <= 1e-5   # fp32 VALU stage
+    assert rel_l2(eng.debug_read("conv2"), cat("conv2", lambda t: t.permute(0, 2, 3, 1))) <= tol["rel"]
+    assert rel_l2(eng.debug_read("conv3"), cat("conv3", lambda t: t.permute(0, 3, 2, 1))) <= tol["rel"]
+    for k in ("enc_in", "enc_layer0", "enc_last", "audio_embeds"):
+        assert rel_l2(eng.debug_read(k), cat(k)) <= tol["rel"], k
+    for b, e in enumerate(embeds):
+        assert e.shape == tuple(res[b].taps["audio_embeds"].shape)
+    prompts = [HipEngine.build_prompt(r.num_audio_tokens) for r in res]
+    logits, nxt = eng.prefill(prompts)
+    for k in ("dec_embed", "dec_layer0", "dec_last_hidden"):
+        assert rel_l2(eng.debug_read(k), cat(k)) <= tol["rel"], k
+    worst = 0.0
+    for b in range(len(clips)):
+        worst = max(worst, float(np.abs(logits[b] - res[b].step_logits[0].numpy()).max()))
+    # teacher-forced decode keeps engine and oracle on the same token history
+    step_tok = [nxt.copy()]
+    for s in range(steps - 1):
+        eng.set_next_tokens([r.all_step_ids[s] for r in res])
+        lg, nx, _ = eng.decode_step()
+        step_tok.append(nx.copy())
+        for b in range(len(clips)):
+            worst = max(worst, float(np.abs(lg[b] - res[b].step_logits[s + 1].numpy()).max()))
+    assert worst <= tol["logit"], worst
+    for b in range(len(clips)):
+        for s in range(steps):
+            top = res[b].step_logits[s].topk(2).values
+            if precise or float(top[0] - top[1]) > 2 * worst:
+                assert int(step_tok[s][b]) == res[b].all_step_ids[s], (b, s)
+    # free-running whole path (graph-replayed decode)
+    ids = eng.transcribe_batch(clips, None, max_new=steps, fixed_new_tokens=steps)
+    if precise:
+        for b in range(len(clips)):
+            assert ids[b] == res[b].all_step_ids[:steps]
+    t = eng.timings()
+    assert t["batch"] == len(clips) and t["decode_steps"] == steps - 1 and t["total_ms"] > 0
+    eng.close()
+    return worst
+
+
+@pytest.mark.parametrize("precise", [True, False])
+def test_stage_parity_tiny_ragged_batch(tiny_dir, precise):
+    """B=3 ragged utterances (10 chunks -> two attention windows; 2.17 s; a length that is not a multiple of
+    the hop): batched results must equal running the reference once per utterance."""
+    clips = [synthetic.synthetic_clip(0, 9.3), synthetic.synthetic_clip(1, 2.17), synthetic.synthetic_clip(2, 4.0)[:63999]]
+    _stage_check(tiny_dir, clips, precise)
+
+
+def test_stage_parity_untied_gqa4_sharded(tiny_untied_dir):
+    _stage_check(tiny_untied_dir, [synthetic.synthetic_clip(2, 4.0)], True)
+
+
+def test_batch_above_gemv_path(tiny_dir):
+    """B=6 > 4 switches the decode step from the GEMV path to the GEMM path."""
+    clips = [synthetic.synthetic_clip(10 + i, 1.5 + 0.37 * i) for i in range(6)]
+    _stage_check(tiny_dir, clips, True, steps=3)
+
+
+def test_graph_replay_equals_eager(tiny_dir):
+    clip = synthetic.synthetic_clip(4, 3.0)
+    out = []
+    for g in (True, False):
+        eng = HipEngine(tiny_dir, 0, use_graph=g, max_new_tokens=16)
+        out.append(eng.transcribe_batch([clip], None, max_new=8, fixed_new_tokens=8)[0])
+        if g:  # second batch of a different shape re-captures the graph
+            out.append(eng.transcribe_batch([clip, clip[:20000]], None, max_new=8, fixed_new_tokens=8)[0])
+        eng.close()
+    assert out[0] == out[1] == out[2] and len(out[0]) == 8
+
+
+def test_eos_stops_generation(tmp_path):
+    """A checkpoint whose lm_head always prefers an EOS id: generated_ids is empty (inference.rs:163-167)."""
+    d = synthetic.write_checkpoint(str(tmp_path / "eos"), "tiny_untied", seed=4, eos_trap=True)
+    clip = synthetic.synthetic_clip(5, 2.0)
+    ref = O.AsrOracle(d).transcribe_ids(clip, max_new_tokens=16)
+    assert ref.ids == [] and ref.all_step_ids[0] in (151643, 151645)
+    eng = HipEngine(d, 0, precise=True, max_new_tokens=16)
+    assert eng.transcribe_batch([clip], None, max_new=16) == [[]]
+    # the cap also bounds a run that never sees EOS
+    eng.close()
+
+
+def test_max_new_cap_without_eos(tiny_dir):
+    eng = HipEngine(tiny_dir, 0, max_new_tokens=64)
+    ids = eng.transcribe_batch([synthetic.synthetic_clip(6, 2.0)], None, max_new=11)[0]
+    assert len(ids) == 11
+    eng.close()
+
+
+def test_forced_language_prefix(tiny_dir):
+    """inference.rs:246-251: the forced-language prompt appends encode("language X") ids."""
+    clip = synthetic.synthetic_clip(9, 2.0)
+    prefix = [11528, 6364]
+    ref = O.AsrOracle(tiny_dir).transcribe_ids(clip, language_prefix_ids=prefix, fixed_new_tokens=3)
+    eng = HipEngine(tiny_dir, 0, precise=True, max_new_tokens=8)
+    assert eng.transcribe_batch([clip], prefix, max_new=3, fixed_new_tokens=3)[0] == ref.all_step_ids[:3]
+    eng.close()
+
+
+def test_errors_are_reported(tiny_dir):
+    from qwen3_asr_rs_amd.engine import Q3aError
+    eng = HipEngine(tiny_dir, 0)
+    with pytest.raises(Q3aError, match="too short"):
+        eng.mel([np.zeros(100, dtype=np.float32)])
+    eng.mel([synthetic.synthetic_clip(0, 1.0)])
+    eng.encode()
+    with pytest.raises(Q3aError, match="audio_pad"):
+        eng.prefill([[151644, 8948, 198]])
+    eng.close()
+
+
+def test_parity_0p6b_dims_30s_clip():
+    """BASELINE configs[1] shape: 0.6B dims (synthetic weights), one 30 s clip -> 4 attention windows
+    (104,104,104,78), P=405.  Oracle uses last_only=True (same last-row logits, skips the all-position lm_head)."""
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
+    clip = synthetic.synthetic_clip(0, 30.0)
+    steps = 3
+    ref = O.AsrOracle(d).transcribe_ids(clip, fixed_new_tokens=steps, last_only=True, want_taps=True)
+    assert ref.num_audio_tokens == 390 and ref.prompt_len == 405
+    for precise in (True, False):
+        eng = HipEngine(d, 0, precise=precise, max_new_tokens=16)
+        eng.mel([clip])
+        emb = eng.encode()[0]
+        assert rel_l2(emb, ref.taps["audio_embeds"].numpy()) <= TOL[precise]["rel"]
+        logits, nxt = eng.prefill([HipEngine.build_prompt(390)])
+        err = float(np.abs(logits[0] - ref.step_logits[0].numpy()).max())
+        assert err <= TOL[precise]["logit"] * (1 if precise else 2), err
+        if precise:
+            assert int(nxt[0]) == ref.all_step_ids[0]
+            assert eng.transcribe_batch([clip], None, max_new=steps, fixed_new_tokens=steps)[0] == ref.all_step_ids[:steps]
+        prof = eng.profile_decode_step()
+        assert prof["gemv"]["launches"] == 28 * 4 + 1 and abs(prof["gemv"]["weight_bytes"] - 1.192e9) < 2e6
+        eng.close()

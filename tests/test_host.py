@@ -1,0 +1,151 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/q3asr.h declares,
+the host-only entry points (config parse, safetensors loader, arena packer, prompt builder) agree with the
+oracle, and the product path fails loudly without a HIP device (no compute is attempted here)."""
+import ctypes as C
+import json
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import q3asr_oracle as O
+from qwen3_asr_rs_amd import _lib, synthetic
+from qwen3_asr_rs_amd.engine import HipEngine, Q3aError, capitalize_first, parse_asr_output
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "q3asr.h")).read()
+    declared = sorted(set(re.findall(r"\b(q3a_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    assert sorted(_lib.SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(lib, name), f"libq3asr_hip.so does not export {name}"
+
+
+def _arena(lib, model_dir):
+    n = C.c_uint64()
+    assert lib.q3a_arena_bytes(model_dir.encode(), C.byref(n)) == 0, lib.q3a_last_error(None)
+    buf = np.zeros(n.value, dtype=np.uint8)
+    assert lib.q3a_arena_pack(model_dir.encode(), buf.ctypes.data_as(C.c_void_p), n.value) == 0, lib.q3a_last_error(None)
+    return buf
+
+
+def _bf16(t: torch.Tensor) -> np.ndarray:
+    return t.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+
+
+def test_arena_contains_permuted_weights(lib, tiny_dir):
+    """Spot-check the layout transforms against the checkpoint read by the oracle's loader."""
+    buf = _arena(lib, tiny_dir)
+    w = O.load_model_weights(tiny_dir)
+    cfg = synthetic.CONFIG_TINY
+    C_, D = cfg["audio_config"]["downsample_hidden_size"], cfg["audio_config"]["d_model"]
+    magic, version, total, flags = struct.unpack_from("<IIQI", buf.tobytes()[:24])
+    assert magic == 0x41335141 and total == len(buf) and flags == 0
+    raw16 = buf.view(np.uint16)
+
+    def find(needle: np.ndarray) -> int:
+        s, n = raw16.tobytes(), needle.tobytes()
+        return s.find(n)
+
+    # conv2: [Co][Ci][3][3] -> [Co][kh][kw][Ci]
+    c2 = w["thinker.audio_tower.conv2d2.weight"]
+    assert find(_bf16(c2.permute(0, 2, 3, 1).contiguous()).ravel()) >= 0
+    # conv_out: column c*F+f -> f*C+c
+    co = w["thinker.audio_tower.conv_out.weight"]
+    F3 = co.shape[1] // C_
+    assert find(_bf16(co.reshape(D, C_, F3).permute(0, 2, 1).contiguous()).ravel()) >= 0
+    # q|k|v concatenation (decoder layer 1)
+    p = "thinker.model.layers.1.self_attn."
+    qkv = torch.cat([w[p + "q_proj.weight"], w[p + "k_proj.weight"], w[p + "v_proj.weight"]], 0)
+    assert find(_bf16(qkv).ravel()) >= 0
+    # gate/up interleave in 16-row blocks
+    g, u = w["thinker.model.layers.0.mlp.gate_proj.weight"], w["thinker.model.layers.0.mlp.up_proj.weight"]
+    I, H = g.shape
+    gu = torch.stack([g.reshape(I // 16, 16, H), u.reshape(I // 16, 16, H)], 1).reshape(2 * I, H)
+    assert find(_bf16(gu).ravel()) >= 0
+    # embedding copied verbatim
+    assert find(_bf16(w["thinker.model.embed_tokens.weight"][:64]).ravel()) >= 0
+
+
+def test_sharded_and_untied_checkpoint_packs(lib, tiny_untied_dir):
+    buf = _arena(lib, tiny_untied_dir)
+    w = O.load_model_weights(tiny_untied_dir)
+    s = buf.tobytes()
+    assert s.find(_bf16(w["thinker.lm_head.weight"][:32]).tobytes()) >= 0
+    assert s.find(_bf16(w["thinker.model.embed_tokens.weight"][:32]).tobytes()) >= 0
+
+
+def test_missing_weight_reports_key(lib, tmp_path):
+    d = synthetic.write_checkpoint(str(tmp_path / "m"), "tiny", seed=3)
+    # drop one tensor from the safetensors header
+    p = os.path.join(d, "model.safetensors")
+    raw = open(p, "rb").read()
+    (hl,) = struct.unpack("<Q", raw[:8])
+    hdr = json.loads(raw[8:8 + hl])
+    del hdr["thinker.model.norm.weight"]
+    hj = json.dumps(hdr).encode()
+    open(p, "wb").write(struct.pack("<Q", len(hj)) + hj + raw[8 + hl:])
+    n = C.c_uint64()
+    assert lib.q3a_arena_bytes(d.encode(), C.byref(n)) == 0
+    buf = np.zeros(n.value, dtype=np.uint8)
+    assert lib.q3a_arena_pack(d.encode(), buf.ctypes.data_as(C.c_void_p), n.value) != 0
+    assert b"Weight not found: thinker.model.norm.weight" in lib.q3a_last_error(None)  # weights.rs:196
+
+
+def test_no_weights_and_bad_config(lib, tmp_path):
+    d = tmp_path / "empty"
+    d.mkdir()
+    n = C.c_uint64()
+    assert lib.q3a_arena_bytes(str(d).encode(), C.byref(n)) != 0  # no config.json
+    (d / "config.json").write_text(json.dumps({"thinker_config": synthetic.CONFIG_TINY}))
+    assert lib.q3a_arena_bytes(str(d).encode(), C.byref(n)) == 0
+    buf = np.zeros(n.value, dtype=np.uint8)
+    assert lib.q3a_arena_pack(str(d).encode(), buf.ctypes.data_as(C.c_void_p), n.value) != 0
+    assert b"No model weights found" in lib.q3a_last_error(None)  # weights.rs:21-24
+    bad = dict(synthetic.CONFIG_TINY)
+    bad["text_config"] = dict(bad["text_config"], head_dim=64)
+    (d / "config.json").write_text(json.dumps({"thinker_config": bad}))
+    assert lib.q3a_arena_bytes(str(d).encode(), C.byref(n)) != 0
+    assert b"head_dim" in lib.q3a_last_error(None)
+
+
+def test_config_defaults_match_reference(lib, tmp_path):
+    """An empty thinker_config must give the serde defaults of src/config.rs (0.6B dims)."""
+    d = tmp_path / "dflt"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({"thinker_config": {"audio_config": {}, "text_config": {}}}))
+    n = C.c_uint64()
+    assert lib.q3a_arena_bytes(str(d).encode(), C.byref(n)) == 0
+    cfg = O.AsrConfig.from_file(str(d / "config.json"))
+    assert cfg.audio.d_model == 896 and cfg.text.num_hidden_layers == 28 and cfg.text.mrope_section == [24, 20, 20]
+    # 782.4 M parameters -> ~1.56 GB of bf16 plus f32 vectors and alignment
+    assert 1.55e9 < n.value < 1.60e9
+
+
+def test_prompt_and_lengths_match_oracle(lib):
+    for T in (0, 1, 54, 390):
+        for prefix in (None, [5, 6, 7]):
+            ids = HipEngine.build_prompt(T, prefix)
+            ref, _ = O.build_prompt(T, prefix)
+            assert ids.tolist() == ref
+    for n in (161, 16000, 66560, 480000, 480001):
+        assert lib.q3a_num_frames(n) == (n + 159) // 160
+
+
+def test_engine_fails_loudly_without_gpu(lib, tiny_dir):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(Q3aError, match="no HIP device"):
+        HipEngine(tiny_dir, 0)
+
+
+def test_output_parsing_mirror():
+    for raw, forced in [("language English<asr_text>Hi.", False), ("language Chinese 你好", False), ("x", False), (" y ", True)]:
+        assert parse_asr_output(raw, forced) == O.parse_asr_output(raw, forced)
+    assert capitalize_first("chinese") == "Chinese"
