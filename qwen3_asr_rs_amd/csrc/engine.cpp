@@ -113,7 +113,8 @@ struct q3a_engine {
   DevBuf enc_x, enc_ln, enc_qkv, enc_ctx, enc_ffn, enc_segs, audio_embeds;
   DevBuf ids, audio_rowmap, row_seq, row_pos, dec_segs, last_rows;
   DevBuf dec_x, dec_ln, dec_qkv, dec_ctx, dec_act, kcache, vcache;
-  DevBuf x_dec, d_pos, next_tok, out_ids, step_count, done, s_ln, s_qkv, s_ctx, s_act, logits, forced_tok;
+  DevBuf x_dec, d_pos, next_tok, out_ids, step_count, done, s_ln, s_qkv, s_ctx, s_act, logits, forced_tok, part_val, part_idx;
+  int part_stride = 0;
   size_t kv_layer_elems = 0;
 
   // ---- graph ----
@@ -440,6 +441,8 @@ struct q3a_engine {
     out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
     s_ln.ensure((size_t)b * H * 4); s_qkv.ensure((size_t)b * d.qkv_dim() * 4); s_ctx.ensure((size_t)b * d.q_dim() * 4);
     s_act.ensure((size_t)b * d.inter * 4); logits.ensure((size_t)b * d.vocab * 4);
+    part_stride = std::max(128, (d.vocab + 3) / 4);  // >= blocks of the lm_head GEMV at 1 row per wave
+    part_val.ensure((size_t)b * part_stride * 4); part_idx.ensure((size_t)b * part_stride * 4);
     HIPCHK(hipMemsetAsync(step_count.p, 0, (size_t)b * 4, stream));
     HIPCHK(hipMemsetAsync(done.p, 0, (size_t)b, stream));
     HIPCHK(hipMemsetAsync(out_ids.p, 0, (size_t)b * max_new * 4, stream));
@@ -449,22 +452,28 @@ struct q3a_engine {
   void* kc_layer(int l) { return (uint8_t*)kcache.p + (size_t)l * kv_layer_elems * kv_elem(); }
   void* vc_layer(int l) { return (uint8_t*)vcache.p + (size_t)l * kv_layer_elems * kv_elem(); }
 
-  // final norm + lm_head on x_dec -> logits, then argmax/finalize
+  // final norm + lm_head on x_dec -> logits (+ block argmax partials), then argmax/finalize
   void run_head(int advance) {
     const int S = B, H = d.hidden, V = d.vocab;
     const double wbytes = 2.0 * V * H;
+    int n_part = 0;
     if (S <= 4) {
       GemvArgs g{};
       g.x = x_dec.as<float>(); g.ldx = H; g.rms_w = wf(L.final_norm); g.eps = d.rms_eps;
-      g.W = wh(L.lm_head); g.N = V; g.K = H; g.mode = 0; g.out = logits.as<float>(); g.ldo = V;
+      g.W = wh(L.lm_head); g.N = V; g.K = H; g.mode = 3; g.out = logits.as<float>(); g.ldo = V;
+      g.part_val = part_val.as<float>(); g.part_idx = part_idx.as<int>(); g.part_stride = part_stride;
+      n_part = gemv_blocks(g);
       timed(Q3A_KC_GEMV, wbytes, [&] { KCHK(launch_gemv(g, S, stream)); });
     } else {
       timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(L.final_norm), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
       GemmEpilogue ep; ep.out = logits.as<float>(); ep.ldo = V;
       timed(Q3A_KC_GEMM, wbytes, [&] { KCHK(launch_gemm(s_ln.as<float>(), H, wh(L.lm_head), S, V, H, ep, false, precise(), stream)); });
+      n_part = 128;
+      timed(Q3A_KC_ARGMAX, 0, [&] { KCHK(launch_argmax_partials(logits.as<float>(), V, S, part_val.as<float>(), part_idx.as<int>(), part_stride, n_part, stream)); });
     }
     FinalizeArgs f{};
-    f.logits = logits.as<float>(); f.V = V; f.next_tok = next_tok.as<int>(); f.out_ids = out_ids.as<int>();
+    f.part_val = part_val.as<float>(); f.part_idx = part_idx.as<int>(); f.part_stride = part_stride; f.n_part = n_part;
+    f.V = V; f.next_tok = next_tok.as<int>(); f.out_ids = out_ids.as<int>();
     f.out_stride = max_new; f.step_count = step_count.as<int>(); f.pos = d_pos.as<int>(); f.advance = advance;
     f.done = done.as<uint8_t>(); f.embed = wh(L.embed); f.H = H; f.x_next = x_dec.as<float>(); f.eos0 = kEos0; f.eos1 = kEos1;
     timed(Q3A_KC_ARGMAX, 0, [&] { KCHK(launch_argmax_finalize(f, S, stream)); });
@@ -583,8 +592,8 @@ struct q3a_engine {
 
   std::string make_graph_sig() const {
     char buf[256];
-    snprintf(buf, sizeof(buf), "%d/%d/%d/%p/%p/%p/%p/%p/%p/%p", B, max_ctx, max_new, kcache.p, vcache.p, x_dec.p,
-             logits.p, s_qkv.p, out_ids.p, rope_cos.p);
+    snprintf(buf, sizeof(buf), "%d/%d/%d/%p/%p/%p/%p/%p/%p/%p/%p", B, max_ctx, max_new, kcache.p, vcache.p, x_dec.p,
+             logits.p, s_qkv.p, out_ids.p, rope_cos.p, part_val.p);
     return buf;
   }
 
@@ -693,7 +702,7 @@ struct q3a_engine {
                       &mel, &gmax, &d_chunk_utt, &d_chunk_frame0, &conv1, &conv2, &conv3, &conv3_rowmap, &convout_rowmap,
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
                       &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
-                      &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok};
+                      &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx};
     for (auto* b : bufs) b->release();
     for (auto& kv : taps) kv.second.release();
     if (own_arena && arena) (void)hipFree(arena);

@@ -16,6 +16,20 @@
 #include "kernels.h"
 
 namespace q3a {
+
+int gemv_rows_per_wave(const GemvArgs& a) {  // physical rows per wave
+  const int logical = (a.mode == 2) ? a.N / 2 : a.N;
+  if (logical >= 32768) return 4;
+  if (logical >= 4096 || a.mode == 2) return 2;
+  return 1;
+}
+int gemv_blocks(const GemvArgs& a) {
+  const int pr = gemv_rows_per_wave(a);
+  const int rows_per_wave = (a.mode == 2) ? pr / 2 : pr;
+  const int logical = (a.mode == 2) ? a.N / 2 : a.N;
+  return (logical + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+}
+
 namespace {
 
 // --------------------------------------------------------------------------------------------------
@@ -83,39 +97,21 @@ __global__ __launch_bounds__(256) void qknorm_rope_kv_kernel(RopeKvArgs a, int r
 }
 
 // --------------------------------------------------------------------------------------------------
-// GEMV: PR physical weight rows per wave, NB activation rows.
-template <int NB, int PR>
+// GEMV: PR physical weight rows per wave, NB activation rows, PF k-iterations of weights prefetched.
+// Order of work inside a block (everything is latency: a 4-12 MB matrix is ~16-48 KB per CU):
+//   1. issue the first PF x 16-B weight loads of every row this wave owns (they do not depend on x)
+//   2. stage x (times the RMSNorm weight) into LDS while those loads fly, accumulate sum(x^2)
+//   3. FMA; the RMSNorm scale 1/sqrt(mean(x^2)+eps) is a scalar, so it multiplies the finished dot
+//      product instead of every x (same value up to fp32 rounding of the reference's (x*rstd)*w order)
+//   4. epilogue: bias / residual / SiLU(gate)*up / logits + per-block argmax partial
+template <int NB, int PR, int PF>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [NB][K]
-  __shared__ float red[4];
+  __shared__ float red[NB][4];
+  __shared__ float am_v[4][NB];
+  __shared__ int am_i[4][NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
-  // ---- stage x (optionally RMS-normalised) ----
-  for (int b = 0; b < NB; ++b) {
-    const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)b * a.ldx);
-    float4* dst = reinterpret_cast<float4*>(xs + (size_t)b * K);
-    float ss = 0.f;
-    for (int i = tid; i < K / 4; i += 256) {
-      const float4 v = src[i];
-      dst[i] = v;
-      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    }
-    if (a.rms_w) {
-      ss = wave_sum(ss);
-      __syncthreads();
-      if (lane == 0) red[wave] = ss;
-      __syncthreads();
-      const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + a.eps);
-      for (int i = tid; i < K / 4; i += 256) {
-        float4 v = dst[i];
-        const float4 w = reinterpret_cast<const float4*>(a.rms_w)[i];
-        v.x = (v.x * rstd) * w.x; v.y = (v.y * rstd) * w.y; v.z = (v.z * rstd) * w.z; v.w = (v.w * rstd) * w.w;
-        dst[i] = v;
-      }
-    }
-  }
-  __syncthreads();
-
   const bool glu = a.mode == 2;
   const int g = blockIdx.x * 4 + wave;
   int prow[PR];
@@ -129,17 +125,45 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     }
     if (prow[i] >= a.N) prow[i] = -1;
   }
+  // ---- 1. weight prefetch ----
+  uint4 wq[PF][PR];
+#pragma unroll
+  for (int it = 0; it < PF; ++it) {
+    const int k = lane * 8 + it * 512;
+#pragma unroll
+    for (int i = 0; i < PR; ++i)
+      wq[it][i] = (prow[i] >= 0 && k < K) ? *reinterpret_cast<const uint4*>(a.W + (size_t)prow[i] * K + k)
+                                          : make_uint4(0u, 0u, 0u, 0u);
+  }
+  // ---- 2. stage x * rms_w ----
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)b * a.ldx);
+    float4* dst = reinterpret_cast<float4*>(xs + (size_t)b * K);
+    float ss = 0.f;
+    for (int i = tid; i < K / 4; i += 256) {
+      float4 v = src[i];
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      if (a.rms_w) {
+        const float4 w = reinterpret_cast<const float4*>(a.rms_w)[i];
+        v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w;
+      }
+      dst[i] = v;
+    }
+    if (a.rms_w) {
+      ss = wave_sum(ss);
+      if (lane == 0) red[b][wave] = ss;
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. dot products ----
   float acc[PR][NB];
 #pragma unroll
   for (int i = 0; i < PR; ++i)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[i][b] = 0.f;
-
-  for (int k = lane * 8; k < K; k += 512) {
-    uint4 w[PR];
-#pragma unroll
-    for (int i = 0; i < PR; ++i)
-      w[i] = prow[i] >= 0 ? *reinterpret_cast<const uint4*>(a.W + (size_t)prow[i] * K + k) : make_uint4(0u, 0u, 0u, 0u);
+  auto fma8 = [&](const uint4 (&w)[PR], int k) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const float4 xa = *reinterpret_cast<const float4*>(xs + (size_t)b * K + k);
@@ -152,12 +176,64 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         acc[i][b] = s;
       }
     }
+  };
+#pragma unroll
+  for (int it = 0; it < PF; ++it) {
+    const int k = lane * 8 + it * 512;
+    if (k < K) fma8(wq[it], k);
+  }
+  for (int k = lane * 8 + PF * 512; k < K; k += 512) {
+    uint4 w[PR];
+#pragma unroll
+    for (int i = 0; i < PR; ++i)
+      w[i] = prow[i] >= 0 ? *reinterpret_cast<const uint4*>(a.W + (size_t)prow[i] * K + k) : make_uint4(0u, 0u, 0u, 0u);
+    fma8(w, k);
   }
 #pragma unroll
   for (int i = 0; i < PR; ++i)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[i][b] = wave_sum(acc[i][b]);
+  if (a.rms_w) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float rstd = 1.0f / sqrtf((red[b][0] + red[b][1] + red[b][2] + red[b][3]) / (float)K + a.eps);
+#pragma unroll
+      for (int i = 0; i < PR; ++i) acc[i][b] *= rstd;
+    }
+  }
 
+  // ---- 4. epilogue ----
+  if (a.mode == 3) {  // logits + argmax partial (first-index tie-break: rows ascend with i, wave, block)
+    float bv[NB];
+    int bi[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { bv[b] = -INFINITY; bi[b] = 0x7fffffff; }
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+      if (prow[i] < 0) continue;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float v = acc[i][b];
+        if (a.bias) v += a.bias[prow[i]];
+        if (lane == 0 && a.out) a.out[(size_t)b * a.ldo + prow[i]] = v;
+        if (v > bv[b]) { bv[b] = v; bi[b] = prow[i]; }
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { am_v[wave][b] = bv[b]; am_i[wave][b] = bi[b]; }
+    }
+    __syncthreads();
+    if (tid < NB) {
+      float v = am_v[0][tid];
+      int ix = am_i[0][tid];
+      for (int w = 1; w < 4; ++w)
+        if (am_v[w][tid] > v || (am_v[w][tid] == v && am_i[w][tid] < ix)) { v = am_v[w][tid]; ix = am_i[w][tid]; }
+      a.part_val[(size_t)tid * a.part_stride + blockIdx.x] = v;
+      a.part_idx[(size_t)tid * a.part_stride + blockIdx.x] = ix;
+    }
+    return;
+  }
   if (lane == 0) {
     if (!glu) {
 #pragma unroll
@@ -188,51 +264,58 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   }
 }
 
-template <int NB, int PR>
+template <int NB, int PR, int PF>
 void gemv_launch_t(const GemvArgs& a, hipStream_t s) {
-  const int rows_per_wave = (a.mode == 2) ? PR / 2 : PR;
-  const int logical = (a.mode == 2) ? a.N / 2 : a.N;
-  const int blocks = (logical + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
-  hipLaunchKernelGGL((gemv_kernel<NB, PR>), dim3(blocks), dim3(256), (size_t)NB * a.K * sizeof(float), s, a);
+  hipLaunchKernelGGL((gemv_kernel<NB, PR, PF>), dim3(gemv_blocks(a)), dim3(256), (size_t)NB * a.K * sizeof(float), s, a);
 }
 template <int NB>
 void gemv_launch_nb(const GemvArgs& a, hipStream_t s) {
-  const int logical = (a.mode == 2) ? a.N / 2 : a.N;
-  if (logical >= 32768) gemv_launch_t<NB, 4>(a, s);
-  else if (logical >= 4096 || a.mode == 2) gemv_launch_t<NB, 2>(a, s);
-  else gemv_launch_t<NB, 1>(a, s);
+  const int pr = gemv_rows_per_wave(a);
+  if (pr == 4) gemv_launch_t<NB, 4, 2>(a, s);
+  else if (pr == 2) gemv_launch_t<NB, 2, 4>(a, s);
+  else gemv_launch_t<NB, 1, 6>(a, s);
 }
 
 // --------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lane_bcast(float v, int lane_const) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
+// DPP sum over the 16 lanes of a row (all 16 lanes end up with the total)
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
 }
 
-template <typename KVT> struct Row64;  // 64 consecutive head dims of one cached key -> registers
-template <> struct Row64<float> {
-  static __device__ __forceinline__ void load(const float* p, float (&r)[64]) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float4 v = reinterpret_cast<const float4*>(p)[i];
-      r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
-    }
+template <typename KVT> struct Frag16;  // 16 bytes of a cached key/value row -> floats
+template <> struct Frag16<uint16_t> {
+  static constexpr int DPL = 8;
+  static __device__ __forceinline__ void unpack(const uint4& r, float (&f)[8]) {
+    f[0] = bf16lo(r.x); f[1] = bf16hi(r.x); f[2] = bf16lo(r.y); f[3] = bf16hi(r.y);
+    f[4] = bf16lo(r.z); f[5] = bf16hi(r.z); f[6] = bf16lo(r.w); f[7] = bf16hi(r.w);
   }
 };
-template <> struct Row64<uint16_t> {
-  static __device__ __forceinline__ void load(const uint16_t* p, float (&r)[64]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint4 v = reinterpret_cast<const uint4*>(p)[i];
-      r[8 * i] = bf16lo(v.x); r[8 * i + 1] = bf16hi(v.x); r[8 * i + 2] = bf16lo(v.y); r[8 * i + 3] = bf16hi(v.y);
-      r[8 * i + 4] = bf16lo(v.z); r[8 * i + 5] = bf16hi(v.z); r[8 * i + 6] = bf16lo(v.w); r[8 * i + 7] = bf16hi(v.w);
-    }
+template <> struct Frag16<float> {
+  static constexpr int DPL = 4;
+  static __device__ __forceinline__ void unpack(const uint4& r, float (&f)[4]) {
+    f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
   }
 };
 
 constexpr int DA_WAVES = 8;
 
+// One workgroup per (sequence, kv head).  Cache rows are read with fully coalesced 16-B-per-lane loads:
+// LPK lanes share one key (each owns DPL head dims), a wave instruction covers KPI consecutive keys.
+// Scores need a DPP reduction over the LPK lanes; P.V needs no cross-lane traffic until the very end.
 template <int GROUP, typename KVT>
 __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnArgs a) {
+  constexpr int DPL = Frag16<KVT>::DPL;  // head dims per lane: 8 (bf16) / 4 (f32)
+  constexpr int LPK = 128 / DPL;         // lanes per key: 16 / 32
+  constexpr int KPI = 64 / LPK;          // keys per load instruction: 4 / 2
+  constexpr int NI = 8;                  // load instructions per key block (K and V: 2*NI*4 raw VGPRs in flight)
+  constexpr int KG = KPI * NI;           // keys per block: 32 / 16
   __shared__ float q_s[GROUP][128];
   __shared__ float k_s[128];
   __shared__ float v_s[128];
@@ -240,11 +323,30 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   __shared__ float co[DA_WAVES][GROUP][128];
   const int s = blockIdx.y, kvh = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane % LPK, kq = lane / LPK;
   const int pos = a.pos[s];
   const int qkv_dim = (a.n_q + 2 * a.n_kv) * 128;
   const float* row = a.qkv + (size_t)s * qkv_dim;
   KVT* kc = reinterpret_cast<KVT*>(a.kcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
   KVT* vc = reinterpret_cast<KVT*>(a.vcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
+  const int nkeys = pos + 1;
+  const int nblocks = (nkeys + KG - 1) / KG;
+
+  uint4 kraw[NI], vraw[NI];
+  auto load_block = [&](int kb) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int key = kb * KG + i * KPI + kq;
+      if (key < pos) {
+        kraw[i] = *reinterpret_cast<const uint4*>(kc + (size_t)key * 128 + sub * DPL);
+        vraw[i] = *reinterpret_cast<const uint4*>(vc + (size_t)key * 128 + sub * DPL);
+      } else {
+        kraw[i] = make_uint4(0u, 0u, 0u, 0u);
+        vraw[i] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  if (wave < nblocks) load_block(wave);  // cached keys do not depend on the new token: fetch them first
 
   // ---- phase A: normalise/rotate the new q (GROUP heads) and k, append k/v to the cache ----
   if (wave < GROUP) {
@@ -271,87 +373,85 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   }
   __syncthreads();
 
-  // ---- phase B: lane-per-key attention over keys 0..pos (key `pos` comes from LDS) ----
-  float qreg[GROUP][2], oacc[GROUP][2], mrun[GROUP], lrun[GROUP];
+  // ---- phase B ----
+  float qf[GROUP][DPL], acc[GROUP][DPL], mrun[GROUP], lrun[GROUP];
 #pragma unroll
   for (int g = 0; g < GROUP; ++g) {
-    qreg[g][0] = q_s[g][lane];
-    qreg[g][1] = q_s[g][lane + 64];
-    oacc[g][0] = oacc[g][1] = 0.f;
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) { qf[g][e] = q_s[g][sub * DPL + e]; acc[g][e] = 0.f; }
     mrun[g] = -INFINITY;
     lrun[g] = 0.f;
   }
-  const int nkeys = pos + 1;
-  const int ngroups = (nkeys + 63) / 64;
-  for (int kg = wave; kg < ngroups; kg += DA_WAVES) {
-    const int key0 = kg * 64, kj = key0 + lane;
-    const bool has_new = (pos >= key0 && pos < key0 + 64);  // wave-uniform: this key block holds the new token
-    const bool mine = (kj == pos);
-    float sc[GROUP];
+  for (int kb = wave; kb < nblocks; kb += DA_WAVES) {
+    if (kb != wave) load_block(kb);
+    const int key_base = kb * KG + kq;
+    float sc[NI][GROUP];
 #pragma unroll
-    for (int g = 0; g < GROUP; ++g) sc[g] = 0.f;
+    for (int i = 0; i < NI; ++i) {
+      const int key = key_base + i * KPI;
+      float kf[DPL];
+      Frag16<KVT>::unpack(kraw[i], kf);
+      if (key == pos) {
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {  // two passes of 64 dims keep the key row at 64 VGPRs
-      float kreg[64];
-      if (kj < pos) {
-        Row64<KVT>::load(kc + (size_t)kj * 128 + hf * 64, kreg);
-      } else {
-#pragma unroll
-        for (int d = 0; d < 64; ++d) kreg[d] = 0.f;
-      }
-      if (has_new) {
-#pragma unroll
-        for (int d = 0; d < 64; ++d) kreg[d] = mine ? k_s[hf * 64 + d] : kreg[d];
+        for (int e = 0; e < DPL; ++e) kf[e] = k_s[sub * DPL + e];
       }
 #pragma unroll
-      for (int d = 0; d < 64; ++d) {
-        const float kd = kreg[d];
+      for (int g = 0; g < GROUP; ++g) {
+        float p = 0.f;
 #pragma unroll
-        for (int g = 0; g < GROUP; ++g) sc[g] += lane_bcast(qreg[g][hf], d) * kd;
+        for (int e = 0; e < DPL; ++e) p += qf[g][e] * kf[e];
+        p = row16_sum(p);
+        if (LPK == 32) p += __shfl_xor(p, 16, 64);
+        sc[i][g] = (key <= pos) ? p / a.scale_div : -INFINITY;
       }
-      __builtin_amdgcn_sched_barrier(0);  // keep the second half's loads behind the first half's FMAs (VGPR budget)
     }
-    float pr[GROUP];
 #pragma unroll
     for (int g = 0; g < GROUP; ++g) {
-      const bool valid = kj <= pos;
-      const float sv = valid ? sc[g] / a.scale_div : -INFINITY;
-      const float m_new = fmaxf(mrun[g], wave_max(sv));  // finite: every processed block has >= 1 valid key
-      const float alpha = expf(mrun[g] - m_new);
-      const float p = valid ? expf(sv - m_new) : 0.f;
-      lrun[g] = lrun[g] * alpha + wave_sum(p);
-      mrun[g] = m_new;
-      oacc[g][0] *= alpha;
-      oacc[g][1] *= alpha;
-      pr[g] = p;
-    }
-    const int jmax = min(64, nkeys - key0);
-#pragma unroll 8
-    for (int j = 0; j < 64; ++j) {  // j stays wave-uniform (SGPR) -> v_readlane with a scalar lane select
-      if (j < jmax) {
-        float v0, v1;
-        if (key0 + j < pos) {
-          v0 = KvIo<KVT>::load(vc + (size_t)(key0 + j) * 128 + lane);
-          v1 = KvIo<KVT>::load(vc + (size_t)(key0 + j) * 128 + lane + 64);
-        } else {
-          v0 = v_s[lane];
-          v1 = v_s[lane + 64];
-        }
+      float mx = sc[0][g];
 #pragma unroll
-        for (int g = 0; g < GROUP; ++g) {
-          const float pj = lane_bcast(pr[g], j);
-          oacc[g][0] += pj * v0;
-          oacc[g][1] += pj * v1;
-        }
+      for (int i = 1; i < NI; ++i) mx = fmaxf(mx, sc[i][g]);
+      if (LPK == 16) mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(mrun[g], mx);  // finite: key kb*KG <= pos is valid
+      const float alpha = expf(mrun[g] - m_new);
+      mrun[g] = m_new;
+      lrun[g] *= alpha;
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) acc[g][e] *= alpha;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int key = key_base + i * KPI;
+      float vf[DPL];
+      Frag16<KVT>::unpack(vraw[i], vf);
+      if (key == pos) {
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) vf[e] = v_s[sub * DPL + e];
+      }
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g) {
+        const float p = (key <= pos) ? expf(sc[i][g] - mrun[g]) : 0.f;
+        lrun[g] += p;
+#pragma unroll
+        for (int e = 0; e < DPL; ++e) acc[g][e] += p * vf[e];
       }
     }
   }
-  // ---- combine the waves' partial softmaxes ----
+  // fold the KPI key columns of the wave (lanes with equal `sub`) together
 #pragma unroll
   for (int g = 0; g < GROUP; ++g) {
+    if (LPK == 16) lrun[g] += __shfl_xor(lrun[g], 16, 64);
+    lrun[g] += __shfl_xor(lrun[g], 32, 64);
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) {
+      if (LPK == 16) acc[g][e] += __shfl_xor(acc[g][e], 16, 64);
+      acc[g][e] += __shfl_xor(acc[g][e], 32, 64);
+    }
     if (lane == 0) { cm[wave][g] = mrun[g]; cl[wave][g] = lrun[g]; }
-    co[wave][g][lane] = oacc[g][0];
-    co[wave][g][lane + 64] = oacc[g][1];
+    if (kq == 0) {
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) co[wave][g][sub * DPL + e] = acc[g][e];
+    }
   }
   __syncthreads();
   if (wave < GROUP) {
@@ -375,17 +475,51 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
 }
 
 // --------------------------------------------------------------------------------------------------
+// argmax, stage 1 (GEMM path only; the GEMV lm_head writes its partials itself): block partial maxima
+__global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __restrict__ logits, int V, float* __restrict__ pval,
+                                                             int* __restrict__ pidx, int stride) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const int s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (V + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per, hi = min(V, lo + per);
+  const float* lg = logits + (size_t)s * V;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = lo + tid; i < hi; i += 256) {
+    const float v = lg[i];
+    if (v > best) { best = v; idx = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    pval[(size_t)s * stride + blockIdx.x] = best;
+    pidx[(size_t)s * stride + blockIdx.x] = idx;
+  }
+}
+
+// argmax, stage 2 + bookkeeping of the greedy loop
 __global__ __launch_bounds__(1024) void argmax_finalize_kernel(FinalizeArgs a) {
   __shared__ float bv[16];
   __shared__ int bi[16];
   __shared__ int tok_s;
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* lg = a.logits + (size_t)s * a.V;
+  const float* pv = a.part_val + (size_t)s * a.part_stride;
+  const int* pi = a.part_idx + (size_t)s * a.part_stride;
   float best = -INFINITY;
   int idx = 0x7fffffff;
-  for (int i = tid; i < a.V; i += 1024) {
-    const float v = lg[i];
-    if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+  for (int i = tid; i < a.n_part; i += 1024) {
+    const float v = pv[i];
+    const int ix = pi[i];
+    if (v > best || (v == best && ix < idx)) { best = v; idx = ix; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -442,14 +576,16 @@ const char* launch_qknorm_rope_kv(const RopeKvArgs& a, int rows, bool kv_f32, hi
 const char* launch_gemv(const GemvArgs& a0, int NB, hipStream_t s) {
   if (a0.K % 8 != 0) return "gemv: K must be a multiple of 8";
   if (a0.mode == 2 && a0.N % 32 != 0) return "gemv: GLU needs N % 32 == 0";
+  if (a0.mode == 3 && (!a0.part_val || !a0.part_idx || gemv_blocks(a0) > a0.part_stride)) return "gemv: argmax partial buffer missing/too small";
   if ((size_t)a0.K * 4 > 64 * 1024) return "gemv: K too large for the LDS staging buffer";
   const int nb_cap = (int)((64 * 1024) / ((size_t)a0.K * 4));  // rows of x that fit in 64 KiB of LDS
   int done = 0;
   while (done < NB) {
     GemvArgs a = a0;
     a.x = a0.x + (size_t)done * a0.ldx;
-    a.out = a0.out + (size_t)done * a0.ldo;
+    if (a0.out) a.out = a0.out + (size_t)done * a0.ldo;
     if (a0.resid) a.resid = a0.resid + (size_t)done * a0.ldo;
+    if (a0.part_val) { a.part_val = a0.part_val + (size_t)done * a0.part_stride; a.part_idx = a0.part_idx + (size_t)done * a0.part_stride; }
     int nb = NB - done;
     if (nb > nb_cap) nb = nb_cap;
     if (nb >= 4) { nb = 4; gemv_launch_nb<4>(a, s); }
@@ -477,6 +613,13 @@ const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipS
   return nullptr;
 }
 
+const char* launch_argmax_partials(const float* logits, int V, int S, float* pval, int* pidx, int stride, int nblk,
+                                   hipStream_t s) {
+  if (S <= 0) return nullptr;
+  if (nblk > stride) return "argmax: partial buffer too small";
+  hipLaunchKernelGGL(argmax_partial_kernel, dim3(nblk, S), dim3(256), 0, s, logits, V, pval, pidx, stride);
+  return nullptr;
+}
 const char* launch_argmax_finalize(const FinalizeArgs& a, int S, hipStream_t s) {
   if (S <= 0) return nullptr;
   hipLaunchKernelGGL(argmax_finalize_kernel, dim3(S), dim3(1024), 0, s, a);

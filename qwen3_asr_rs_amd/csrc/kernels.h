@@ -100,11 +100,15 @@ struct GemvArgs {
   float eps;
   const uint16_t* W; int N; int K;
   const float* bias;            // [N] or null
-  int mode;                     // 0: store, 1: out = resid + y, 2: GLU (W rows in [16 gate|16 up] blocks; N = 2*inter)
+  int mode;                     // 0: store, 1: out = resid + y, 2: GLU (W rows in [16 gate|16 up] blocks; N = 2*inter),
+                                // 3: logits (out nullable) + per-block argmax partials
   float* out; int ldo;
   const float* resid;
+  float* part_val; int* part_idx; int part_stride;  // mode 3: [NB][part_stride], entry = blockIdx.x
 };
 const char* launch_gemv(const GemvArgs& a, int NB, hipStream_t s);
+int gemv_blocks(const GemvArgs& a);        // grid size launch_gemv uses (= number of argmax partials in mode 3)
+int gemv_rows_per_wave(const GemvArgs& a);
 
 struct DecodeAttnArgs {
   const float* qkv;            // [S][qkv_dim] fp32 (raw projections of the current token)
@@ -119,7 +123,9 @@ struct DecodeAttnArgs {
 const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
 
 struct FinalizeArgs {
-  const float* logits;     // [S][V]
+  const float* part_val;   // [S][part_stride] block-partial maxima ...
+  const int* part_idx;     // ... and their vocabulary indices
+  int part_stride, n_part;
   int V;
   int* next_tok;           // [S] token to feed next (written)
   int* out_ids;            // [S][out_stride] generated ids (written at step_count[s])
@@ -132,6 +138,9 @@ struct FinalizeArgs {
   float* x_next;           // [S][H] embedding of the chosen token
   int eos0, eos1;
 };
+// block partials of logits [S][V] (GEMM decode path; the GEMV lm_head produces its own)
+const char* launch_argmax_partials(const float* logits, int V, int S, float* pval, int* pidx, int stride, int nblk,
+                                   hipStream_t s);
 const char* launch_argmax_finalize(const FinalizeArgs& a, int S, hipStream_t s);
 // x_next[s] = embed[tok[s]]; next_tok[s] = tok[s]  (teacher forcing)
 const char* launch_set_tokens(const int* tok, int S, const uint16_t* embed, int H, float* x_next, int* next_tok, hipStream_t s);
