@@ -34,14 +34,25 @@ def cpu_baseline(model_dir: str, clip: np.ndarray, new_tokens: int) -> dict:
     torch.set_grad_enabled(False)
     orc = O.AsrOracle(model_dir)
     secs = len(clip) / 16000.0
-    t0 = time.time(); orc.transcribe_ids(clip, fixed_new_tokens=2, keep_logits=False); t2 = time.time() - t0
-    t0 = time.time(); orc.transcribe_ids(clip, fixed_new_tokens=8, keep_logits=False); t8 = time.time() - t0
-    t_dec = max((t8 - t2) / 6.0, 0.0)
-    t_front = max(t2 - 2 * t_dec, 0.0)
-    total = t_front + new_tokens * t_dec
-    return {"value": round(secs / total, 3), "unit": "audio-seconds/sec", "cores": torch.get_num_threads(), "kind": "port",
+    all_cores = torch.get_num_threads()
+    best = None
+    # libtorch's default (all cores) is what the reference binary would use; a GEMV-bound decode step often
+    # runs faster on fewer threads, so the better of {all cores, 16 threads} is reported, with its core count.
+    for nt in sorted({all_cores, min(16, all_cores)}, reverse=True):
+        torch.set_num_threads(nt)
+        t0 = time.time(); orc.transcribe_ids(clip, fixed_new_tokens=2, keep_logits=False); t2 = time.time() - t0
+        t0 = time.time(); orc.transcribe_ids(clip, fixed_new_tokens=8, keep_logits=False); t8 = time.time() - t0
+        t_dec = max((t8 - t2) / 6.0, 0.0)
+        t_front = max(t2 - 2 * t_dec, 0.0)
+        total = t_front + new_tokens * t_dec
+        if best is None or total < best[0]:
+            best = (total, nt, t_front, t_dec)
+    torch.set_num_threads(all_cores)
+    total, nt, t_front, t_dec = best
+    return {"value": round(secs / total, 3), "unit": "audio-seconds/sec", "cores": nt, "kind": "port",
             "sample": f"1 clip x {secs:.0f}s: mel+encoder+prefill measured once ({t_front:.2f}s), decode "
-                      f"{t_dec*1e3:.1f} ms/token measured over 6 tokens, extrapolated to {new_tokens} tokens"}
+                      f"{t_dec*1e3:.1f} ms/token measured over 6 tokens, extrapolated to {new_tokens} tokens; "
+                      f"best of {{{all_cores},16}} threads"}
 
 
 def main():

@@ -39,6 +39,39 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // SiLU (reference: Tensor::silu, src/tensor.rs:354-356)
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
+// DPP sum over the 16 lanes of a row: every lane of the row ends up with the row total
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane_uniform) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
+}
+// full-wave sum without LDS traffic: 4 DPP adds + 4 v_readlane
+__device__ __forceinline__ float wave_sum_fast(float v) {
+  v = row16_sum(v);
+  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+
+// One wave per 128-wide head vector; the lane owns dims (lane, lane+64) = the rotate_half partners.
+// per-head RMSNorm (src/layers.rs:303-304,48-54) then RoPE x*cos + rotate_half(x)*sin (layers.rs:361-375)
+__device__ __forceinline__ void head_norm_rope(float& x1, float& x2, const float* __restrict__ w, float eps,
+                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                               int pos, int lane) {
+  const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
+  const float rstd = 1.0f / sqrtf(ss / 128.0f + eps);
+  const float n1 = (x1 * rstd) * w[lane], n2 = (x2 * rstd) * w[lane + 64];
+  const float c = cos_t[(size_t)pos * 64 + lane], sn = sin_t[(size_t)pos * 64 + lane];
+  x1 = n1 * c + (-n2) * sn;  // rotate_half = cat(-x2, x1)
+  x2 = n2 * c + n1 * sn;
+}
+
 // KV-cache element types: bf16 (default) or f32 (precise mode)
 template <typename T> struct KvIo;
 template <> struct KvIo<float> {

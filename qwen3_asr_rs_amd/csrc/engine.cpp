@@ -114,7 +114,8 @@ struct q3a_engine {
   DevBuf ids, audio_rowmap, row_seq, row_pos, dec_segs, last_rows;
   DevBuf dec_x, dec_ln, dec_qkv, dec_ctx, dec_act, kcache, vcache;
   DevBuf x_dec, d_pos, next_tok, out_ids, step_count, done, s_ln, s_qkv, s_ctx, s_act, logits, forced_tok, part_val, part_idx;
-  int part_stride = 0;
+  DevBuf attn_pm, attn_pl, attn_po;
+  int part_stride = 0, attn_nsplit = 0;
   size_t kv_layer_elems = 0;
 
   // ---- graph ----
@@ -443,6 +444,9 @@ struct q3a_engine {
     s_act.ensure((size_t)b * d.inter * 4); logits.ensure((size_t)b * d.vocab * 4);
     part_stride = std::max(128, (d.vocab + 3) / 4);  // >= blocks of the lm_head GEMV at 1 row per wave
     part_val.ensure((size_t)b * part_stride * 4); part_idx.ensure((size_t)b * part_stride * 4);
+    attn_nsplit = (max_ctx + dattn_keys_per_split(kv_f32()) - 1) / dattn_keys_per_split(kv_f32());
+    attn_pm.ensure((size_t)b * d.n_q * attn_nsplit * 4); attn_pl.ensure((size_t)b * d.n_q * attn_nsplit * 4);
+    attn_po.ensure((size_t)b * d.n_q * attn_nsplit * 128 * 4);
     HIPCHK(hipMemsetAsync(step_count.p, 0, (size_t)b * 4, stream));
     HIPCHK(hipMemsetAsync(done.p, 0, (size_t)b, stream));
     HIPCHK(hipMemsetAsync(out_ids.p, 0, (size_t)b * max_new * 4, stream));
@@ -541,7 +545,8 @@ struct q3a_engine {
     const bool gemv = S <= 4;
     DecodeAttnArgs da{};
     da.qkv = s_qkv.as<float>(); da.pos = d_pos.as<int>(); da.eps = d.rms_eps;
-    da.cos_t = rope_cos.as<float>(); da.sin_t = rope_sin.as<float>(); da.out = s_ctx.as<float>();
+    da.cos_t = rope_cos.as<float>(); da.sin_t = rope_sin.as<float>();
+    da.pm = attn_pm.as<float>(); da.pl = attn_pl.as<float>(); da.po = attn_po.as<float>(); da.nsplit = attn_nsplit;
     da.n_q = d.n_q; da.n_kv = d.n_kv; da.max_ctx = max_ctx; da.scale_div = sqrtf((float)d.head_dim);
     for (int li = 0; li < d.dec_layers; ++li) {
       const DecLayerOff& l = L.dec[li];
@@ -559,7 +564,14 @@ struct q3a_engine {
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), stream)); });
       if (gemv) {
         GemvArgs g{};
-        g.x = s_ctx.as<float>(); g.ldx = QD; g.W = wh(l.o_w); g.N = H; g.K = QD; g.bias = o_bias ? wf(l.o_b) : nullptr;
+        if (std::min(S, 4) * d.n_q * attn_nsplit <= GEMV_ATTN_MAX_TABLE) {  // merge the key splits inside the o_proj GEMV
+          g.attn_pm = attn_pm.as<float>(); g.attn_pl = attn_pl.as<float>(); g.attn_po = attn_po.as<float>();
+          g.attn_nsplit = attn_nsplit; g.attn_heads = d.n_q;
+        } else {  // very long contexts: separate merge launch
+          timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream)); });
+          g.x = s_ctx.as<float>();
+        }
+        g.ldx = QD; g.W = wh(l.o_w); g.N = H; g.K = QD; g.bias = o_bias ? wf(l.o_b) : nullptr;
         g.mode = 1; g.out = x_dec.as<float>(); g.ldo = H; g.resid = x_dec.as<float>();
         timed(Q3A_KC_GEMV, 2.0 * H * QD, [&] { KCHK(launch_gemv(g, S, stream)); });
         GemvArgs u{};
@@ -572,6 +584,7 @@ struct q3a_engine {
         timed(Q3A_KC_GEMV, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, stream)); });
       } else {
         const bool sp = precise();
+        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream)); });
         {
           GemmEpilogue ep; ep.out = x_dec.as<float>(); ep.ldo = H; ep.resid = x_dec.as<float>(); ep.bias = o_bias ? wf(l.o_b) : nullptr;
           timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { KCHK(launch_gemm(s_ctx.as<float>(), QD, wh(l.o_w), S, H, QD, ep, false, sp, stream)); });
@@ -593,7 +606,7 @@ struct q3a_engine {
   std::string make_graph_sig() const {
     char buf[256];
     snprintf(buf, sizeof(buf), "%d/%d/%d/%p/%p/%p/%p/%p/%p/%p/%p", B, max_ctx, max_new, kcache.p, vcache.p, x_dec.p,
-             logits.p, s_qkv.p, out_ids.p, rope_cos.p, part_val.p);
+             logits.p, s_qkv.p, out_ids.p, rope_cos.p, attn_po.p);
     return buf;
   }
 
@@ -702,7 +715,7 @@ struct q3a_engine {
                       &mel, &gmax, &d_chunk_utt, &d_chunk_frame0, &conv1, &conv2, &conv3, &conv3_rowmap, &convout_rowmap,
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
                       &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
-                      &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx};
+                      &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po};
     for (auto* b : bufs) b->release();
     for (auto& kv : taps) kv.second.release();
     if (own_arena && arena) (void)hipFree(arena);

@@ -18,10 +18,6 @@
 namespace q3a {
 namespace {
 
-__device__ __forceinline__ float lane_bcast(float v, int lane_const) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
-}
-
 template <typename KVT> struct RowLoad;
 template <> struct RowLoad<float> {
   template <int HD> static __device__ __forceinline__ void load(const float* p, float (&r)[HD]) {

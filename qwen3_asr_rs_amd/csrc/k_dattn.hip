@@ -1,0 +1,254 @@
+// Single-token (decode) attention for gfx950, flash-decoding style.
+//
+// Replaces, for the one new token of every sequence, TextAttention::forward's per-head RMSNorm on q/k
+// (src/layers.rs:303-304), RoPE (layers.rs:307-308,361-375), the KV-cache append (layers.rs:311-319; the
+// reference re-allocates the cache with `cat` every step), repeat_kv (layers.rs:321-324) and
+// softmax(q K^T / sqrt(128)) V (layers.rs:327-335; the decode-step mask of text_decoder.rs:121-131 is
+// all zeros).
+//
+// Grid = (kv head, sequence, key split of 128 keys).  One CU streams only ~25-50 GB/s, so the ~200 KB of
+// K+V a kv head holds at context ~400 must be spread over several CUs: measured 12.8 us with one workgroup
+// per kv head (8 or 16 waves alike) against 6.4 us with 128-key splits.  Every workgroup
+//   * first issues its cache loads (they do not depend on the new token): each wave owns 16 keys and reads
+//     them with fully coalesced 16-B-per-lane loads -- LPK lanes share one key (DPL head dims each), one
+//     wave instruction covers KPI consecutive cache rows;
+//   * meanwhile normalises/rotates q for its GROUP query heads (and, in the split that owns position
+//     `pos`, the new k, and appends k/v to the cache);
+//   * scores: per-lane partial dot over DPL dims + DPP reduction across the LPK lanes; P.V needs no
+//     cross-lane traffic until one fold at the end;
+//   * writes an unnormalised partial (m, l, o[128]) per (sequence, head, split).  The consumer (the
+//     o_proj GEMV in k_gemv.hip, or attn_combine_kernel below) merges the splits -- no second launch on
+//     the GEMV path.
+#include "dev.h"
+#include "kernels.h"
+
+namespace q3a {
+namespace {
+
+template <typename KVT> struct Frag16;  // 16 bytes of a cached key/value row -> floats
+template <> struct Frag16<uint16_t> {
+  static constexpr int DPL = 8;
+  static __device__ __forceinline__ void unpack(const uint4& r, float (&f)[8]) {
+    f[0] = bf16lo(r.x); f[1] = bf16hi(r.x); f[2] = bf16lo(r.y); f[3] = bf16hi(r.y);
+    f[4] = bf16lo(r.z); f[5] = bf16hi(r.z); f[6] = bf16lo(r.w); f[7] = bf16hi(r.w);
+  }
+};
+template <> struct Frag16<float> {
+  static constexpr int DPL = 4;
+  static __device__ __forceinline__ void unpack(const uint4& r, float (&f)[4]) {
+    f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y); f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+  }
+};
+
+constexpr int DA_WAVES = 8;
+
+template <int GROUP, typename KVT>
+__global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnArgs a) {
+  constexpr int DPL = Frag16<KVT>::DPL;   // head dims per lane: 8 (bf16) / 4 (f32)
+  constexpr int LPK = 128 / DPL;          // lanes per key: 16 / 32
+  constexpr int KPI = 64 / LPK;           // keys per load instruction: 4 / 2
+  constexpr int NI = 16 / KPI;            // load instructions per wave: 4 / 8 (16 keys per wave)
+  constexpr int KEYS_PER_WAVE = KPI * NI; // 16
+  constexpr int KEYS_PER_SPLIT = KEYS_PER_WAVE * DA_WAVES;  // 128
+  static_assert(KEYS_PER_SPLIT == (sizeof(KVT) == 2 ? DATTN_KEYS_PER_SPLIT_BF16 : DATTN_KEYS_PER_SPLIT_F32), "split size");
+  __shared__ float q_s[GROUP][128];
+  __shared__ float k_s[128];
+  __shared__ float v_s[128];
+  __shared__ float cm[DA_WAVES][GROUP], cl[DA_WAVES][GROUP];
+  __shared__ float co[DA_WAVES][GROUP][128];
+  const int kvh = blockIdx.x, s = blockIdx.y, sp = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane % LPK, kq = lane / LPK;
+  const int pos = a.pos[s];
+  const int key_lo = sp * KEYS_PER_SPLIT;
+  const size_t pbase = ((size_t)s * a.n_q + (size_t)kvh * GROUP) * a.nsplit + sp;  // + g * nsplit
+  if (key_lo > pos) {  // this split holds no key yet: statistics of an empty set, zeroed output
+    if (tid < GROUP) { a.pm[pbase + (size_t)tid * a.nsplit] = -INFINITY; a.pl[pbase + (size_t)tid * a.nsplit] = 0.f; }
+    if (tid < GROUP * 128) a.po[(pbase + (size_t)(tid >> 7) * a.nsplit) * 128 + (tid & 127)] = 0.f;
+    return;
+  }
+  const bool owner = (pos - key_lo) < KEYS_PER_SPLIT;  // the new token lands in this split
+  const int qkv_dim = (a.n_q + 2 * a.n_kv) * 128;
+  const float* row = a.qkv + (size_t)s * qkv_dim;
+  KVT* kc = reinterpret_cast<KVT*>(a.kcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
+  KVT* vc = reinterpret_cast<KVT*>(a.vcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
+
+  const int key_base = key_lo + wave * KEYS_PER_WAVE + kq;
+  uint4 kraw[NI], vraw[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int key = key_base + i * KPI;
+    if (key < pos) {
+      kraw[i] = *reinterpret_cast<const uint4*>(kc + (size_t)key * 128 + sub * DPL);
+      vraw[i] = *reinterpret_cast<const uint4*>(vc + (size_t)key * 128 + sub * DPL);
+    } else {
+      kraw[i] = make_uint4(0u, 0u, 0u, 0u);
+      vraw[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+
+  // ---- new token: q for the GROUP heads of this kv head; k/v only in the owning split ----
+  if (wave < GROUP) {
+    const int h = kvh * GROUP + wave;
+    float x1 = row[h * 128 + lane], x2 = row[h * 128 + lane + 64];
+    head_norm_rope(x1, x2, a.q_norm, a.eps, a.cos_t, a.sin_t, pos, lane);
+    q_s[wave][lane] = x1;
+    q_s[wave][lane + 64] = x2;
+  } else if (owner && wave == GROUP) {
+    const float* p = row + (a.n_q + kvh) * 128;
+    float x1 = p[lane], x2 = p[lane + 64];
+    head_norm_rope(x1, x2, a.k_norm, a.eps, a.cos_t, a.sin_t, pos, lane);
+    KvIo<KVT>::store(kc + (size_t)pos * 128 + lane, x1);
+    KvIo<KVT>::store(kc + (size_t)pos * 128 + lane + 64, x2);
+    k_s[lane] = KvIo<KVT>::round(x1);
+    k_s[lane + 64] = KvIo<KVT>::round(x2);
+  } else if (owner && wave == GROUP + 1) {
+    const float* p = row + (a.n_q + a.n_kv + kvh) * 128;
+    const float x1 = p[lane], x2 = p[lane + 64];
+    KvIo<KVT>::store(vc + (size_t)pos * 128 + lane, x1);
+    KvIo<KVT>::store(vc + (size_t)pos * 128 + lane + 64, x2);
+    v_s[lane] = KvIo<KVT>::round(x1);
+    v_s[lane + 64] = KvIo<KVT>::round(x2);
+  }
+  __syncthreads();
+
+  // ---- scores for this wave's 16 keys ----
+  float qf[GROUP][DPL];
+#pragma unroll
+  for (int g = 0; g < GROUP; ++g)
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) qf[g][e] = q_s[g][sub * DPL + e];
+  float sc[NI][GROUP];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int key = key_base + i * KPI;
+    float kf[DPL];
+    Frag16<KVT>::unpack(kraw[i], kf);
+    if (key == pos) {
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) kf[e] = k_s[sub * DPL + e];
+    }
+#pragma unroll
+    for (int g = 0; g < GROUP; ++g) {
+      float p = 0.f;
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) p += qf[g][e] * kf[e];
+      p = row16_sum(p);
+      if (LPK == 32) p += __shfl_xor(p, 16, 64);
+      sc[i][g] = (key <= pos) ? p / a.scale_div : -INFINITY;  // layers.rs:327-328 divides after the matmul
+    }
+  }
+  float acc[GROUP][DPL], mw[GROUP], lw[GROUP];
+#pragma unroll
+  for (int g = 0; g < GROUP; ++g) {
+    float mx = sc[0][g];
+#pragma unroll
+    for (int i = 1; i < NI; ++i) mx = fmaxf(mx, sc[i][g]);
+    if (LPK == 16) mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mw[g] = mx;  // -inf when none of this wave's keys exists yet
+    lw[g] = 0.f;
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) acc[g][e] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int key = key_base + i * KPI;
+    float vf[DPL];
+    Frag16<KVT>::unpack(vraw[i], vf);
+    if (key == pos) {
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) vf[e] = v_s[sub * DPL + e];
+    }
+#pragma unroll
+    for (int g = 0; g < GROUP; ++g) {
+      const float p = (key <= pos) ? expf(sc[i][g] - mw[g]) : 0.f;
+      lw[g] += p;
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) acc[g][e] += p * vf[e];
+    }
+  }
+  // fold the KPI key columns of the wave (lanes with equal `sub`)
+#pragma unroll
+  for (int g = 0; g < GROUP; ++g) {
+    if (LPK == 16) lw[g] += __shfl_xor(lw[g], 16, 64);
+    lw[g] += __shfl_xor(lw[g], 32, 64);
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) {
+      if (LPK == 16) acc[g][e] += __shfl_xor(acc[g][e], 16, 64);
+      acc[g][e] += __shfl_xor(acc[g][e], 32, 64);
+    }
+    if (lane == 0) { cm[wave][g] = mw[g]; cl[wave][g] = lw[g]; }
+    if (kq == 0) {
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) co[wave][g][sub * DPL + e] = acc[g][e];
+    }
+  }
+  __syncthreads();
+  // ---- merge the 8 waves, write the split's partial ----
+  if (wave < GROUP) {
+    const int g = wave;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < DA_WAVES; ++w) M = fmaxf(M, cm[w][g]);  // finite: key_lo <= pos
+    float L = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < DA_WAVES; ++w) {
+      const float f = (cm[w][g] == -INFINITY) ? 0.f : expf(cm[w][g] - M);
+      L += cl[w][g] * f;
+      o0 += co[w][g][lane] * f;
+      o1 += co[w][g][lane + 64] * f;
+    }
+    const size_t pi = pbase + (size_t)g * a.nsplit;
+    if (lane == 0) { a.pm[pi] = M; a.pl[pi] = L; }
+    a.po[pi * 128 + lane] = o0;
+    a.po[pi * 128 + lane + 64] = o1;
+  }
+}
+
+// merge of the split partials into [S][n_q*128] (only the GEMM decode path needs it as a separate launch)
+__global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
+                                                           const float* __restrict__ po, int nsplit, float* __restrict__ out) {
+  const size_t sh = blockIdx.x;  // (sequence, head) flattened
+  const int d = threadIdx.x;
+  float M = -INFINITY;
+  for (int sp = 0; sp < nsplit; ++sp) M = fmaxf(M, pm[sh * nsplit + sp]);
+  float L = 0.f, o = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) {
+    const float m = pm[sh * nsplit + sp];
+    if (m == -INFINITY) continue;
+    const float f = expf(m - M);
+    L += pl[sh * nsplit + sp] * f;
+    o += po[(sh * nsplit + sp) * 128 + d] * f;
+  }
+  out[sh * 128 + d] = o / L;
+}
+
+}  // namespace
+
+const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s) {
+  if (S <= 0) return nullptr;
+  if (a.nsplit <= 0 || a.nsplit * dattn_keys_per_split(kv_f32) < a.max_ctx) return "decode_attn: nsplit does not cover max_ctx";
+  const int group = a.n_q / a.n_kv;
+  dim3 grid(a.n_kv, S, a.nsplit), block(DA_WAVES * 64);
+#define Q3A_DA(G)                                                                                   \
+  do {                                                                                              \
+    if (kv_f32) hipLaunchKernelGGL((decode_attn_kernel<G, float>), grid, block, 0, s, a);          \
+    else hipLaunchKernelGGL((decode_attn_kernel<G, uint16_t>), grid, block, 0, s, a);              \
+  } while (0)
+  if (group == 1) Q3A_DA(1);
+  else if (group == 2) Q3A_DA(2);
+  else if (group == 4) Q3A_DA(4);
+  else return "decode_attn: GQA group must be 1, 2 or 4";
+#undef Q3A_DA
+  return nullptr;
+}
+
+const char* launch_attn_combine(const float* pm, const float* pl, const float* po, int nsplit, int S, int n_q, float* out,
+                                hipStream_t s) {
+  if (S <= 0) return nullptr;
+  hipLaunchKernelGGL(attn_combine_kernel, dim3(S * n_q), dim3(128), 0, s, pm, pl, po, nsplit, out);
+  return nullptr;
+}
+
+}  // namespace q3a

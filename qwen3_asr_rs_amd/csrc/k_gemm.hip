@@ -7,10 +7,12 @@
 //     product is fp32-accurate ("precise" mode of the engine).
 //   * W: bf16 [N][K] row-major (K contiguous = the layout nn.Linear checkpoints already have).
 //   * 256 threads = 4 waves (2x2); each wave owns a (BM/2)x(BN/2) tile built from
-//     v_mfma_f32_16x16x32_bf16 fragments; BK = 32; register prefetch of the next K tile overlaps
-//     the MFMAs of the current one.
-//   * LDS rows are 40 bf16 (80 B) wide so the 16 rows a lane group reads with ds_read_b128 fall on
-//     16 distinct 16-B bank slots.
+//     v_mfma_f32_16x16x32_bf16 fragments; register prefetch of the next K tile overlaps the MFMAs of
+//     the current one.  Three tile shapes, picked by how many workgroups the problem yields:
+//     128x128x64 (big M: conv stem, batched encoder), 64x64x128 and 32x32x128 (M ~ 400 prefill /
+//     single-clip encoder shapes, where a deep K tile amortises the global-load latency per barrier).
+//   * LDS rows are BK+8 bf16 wide so the 16 rows a lane group reads with ds_read_b128 fall on
+//     distinct 16-B bank slots.
 //   * blockIdx -> tile uses the bijective XCD remap: consecutive tile ids (which share the W column
 //     panel) run on the same XCD/L2.
 //
@@ -24,8 +26,6 @@ namespace q3a {
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDS_STRIDE = 40;  // bf16 elements per LDS row (32 + 8 pad)
 
 struct DenseA {
   const float* x;
@@ -66,12 +66,16 @@ struct ConvA {
   }
 };
 
-template <int BM, int BN, bool SPLIT, bool GLU, class ALoader>
+template <int BM, int BN, int BK, bool SPLIT, bool GLU, class ALoader>
 __global__ __launch_bounds__(256) void gemm_kernel(ALoader A, const uint16_t* __restrict__ Wt, int M, int N, int K,
                                                    GemmEpilogue ep) {
-  constexpr int A_LOADS = BM / 32;  // float4 loads per thread per K tile (BM rows x 8 float4)
-  constexpr int W_LOADS = BN / 64;  // 16-B loads per thread per K tile (BN rows x 4 chunks)
-  constexpr int MI = BM / 32, NI = BN / 32;  // 16x16 fragments per wave
+  constexpr int LDS_STRIDE = BK + 8;          // bf16 elements per LDS row
+  constexpr int TPR_A = BK / 4, RP_A = 256 / TPR_A;  // threads per A row (float4 each), rows per pass
+  constexpr int TPR_W = BK / 8, RP_W = 256 / TPR_W;  // threads per W row (16 B each), rows per pass
+  constexpr int A_LOADS = BM / RP_A;          // float4 loads per thread per K tile
+  constexpr int W_LOADS = BN / RP_W;          // 16-B loads per thread per K tile
+  constexpr int MI = BM / 32, NI = BN / 32;   // 16x16 fragments per wave
+  static_assert(A_LOADS >= 1 && W_LOADS >= 1 && MI >= 1 && NI >= 1, "tile too small for 256 threads");
   __shared__ __attribute__((aligned(16))) uint16_t As[(SPLIT ? 2 : 1) * BM * LDS_STRIDE];
   __shared__ __attribute__((aligned(16))) uint16_t Ws[BN * LDS_STRIDE];
 
@@ -91,14 +95,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(ALoader A, const uint16_t* __
 
   // ---- per-thread staging assignment ----
   int a_s0[A_LOADS], a_s1[A_LOADS], a_s2[A_LOADS];
-  const int a_c4 = tid & 7;  // which float4 of the 32-float row
+  const int a_c4 = tid % TPR_A;  // which float4 of the BK-float row
+  const int a_r = tid / TPR_A;
 #pragma unroll
-  for (int i = 0; i < A_LOADS; ++i) A.init_row(m0 + (tid >> 3) + i * 32, M, a_s0[i], a_s1[i], a_s2[i]);
-  const int w_chunk = tid & 3;
+  for (int i = 0; i < A_LOADS; ++i) A.init_row(m0 + a_r + i * RP_A, M, a_s0[i], a_s1[i], a_s2[i]);
+  const int w_chunk = tid % TPR_W, w_r = tid / TPR_W;
   const uint16_t* w_ptr[W_LOADS];
 #pragma unroll
   for (int i = 0; i < W_LOADS; ++i) {
-    int n = n0 + (tid >> 2) + i * 64;
+    int n = n0 + w_r + i * RP_W;
     w_ptr[i] = (n < N) ? Wt + (size_t)n * K + w_chunk * 8 : nullptr;
   }
 
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ALoader A, const uint16_t* __
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-      const int row = (tid >> 3) + i * 32;
+      const int row = a_r + i * RP_A;
       const float4 v = a_reg[i];
       uint2 hi;
       hi.x = pack_bf16x2(v.x, v.y);
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ALoader A, const uint16_t* __
     }
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i) {
-      const int row = (tid >> 2) + i * 64;
+      const int row = w_r + i * RP_W;
       *reinterpret_cast<uint4*>(&Ws[row * LDS_STRIDE + w_chunk * 8]) = w_reg[i];
     }
   };
@@ -150,20 +155,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(ALoader A, const uint16_t* __
     store_tile();
     __syncthreads();
     if (kt + 1 < KT) load_tile((kt + 1) * BK);
-    bf16x8_t bfrag[NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-      bfrag[j] = *reinterpret_cast<const bf16x8_t*>(&Ws[(wc * (BN / 2) + j * 16 + frag_row) * LDS_STRIDE + frag_k]);
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int kk = ks * 32 + frag_k;
+      bf16x8_t bfrag[NI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int arow = wr * (BM / 2) + i * 16 + frag_row;
-      const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(&As[arow * LDS_STRIDE + frag_k]);
+      for (int j = 0; j < NI; ++j)
+        bfrag[j] = *reinterpret_cast<const bf16x8_t*>(&Ws[(wc * (BN / 2) + j * 16 + frag_row) * LDS_STRIDE + kk]);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bfrag[j], acc[i][j], 0, 0, 0);
-      if (SPLIT) {
-        const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(&As[(BM + arow) * LDS_STRIDE + frag_k]);
+      for (int i = 0; i < MI; ++i) {
+        const int arow = wr * (BM / 2) + i * 16 + frag_row;
+        const bf16x8_t ah = *reinterpret_cast<const bf16x8_t*>(&As[arow * LDS_STRIDE + kk]);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bfrag[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bfrag[j], acc[i][j], 0, 0, 0);
+        if (SPLIT) {
+          const bf16x8_t al = *reinterpret_cast<const bf16x8_t*>(&As[(BM + arow) * LDS_STRIDE + kk]);
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bfrag[j], acc[i][j], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -209,25 +218,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(ALoader A, const uint16_t* __
   }
 }
 
-template <int BM, int BN, bool SPLIT, bool GLU, class ALoader>
+template <int BM, int BN, int BK, bool SPLIT, bool GLU, class ALoader>
 void launch_one(const ALoader& A, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, SPLIT, GLU, ALoader>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, GLU, ALoader>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
 }
 
+inline long tiles_of(int M, int N, int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); }
+
 template <bool GLU, class ALoader>
-void launch_sized(const ALoader& A, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep, bool split,
-                  hipStream_t s) {
-  // big tiles once they fill the chip twice over, small tiles otherwise (latency-bound shapes)
-  const long big_tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-  const bool big = big_tiles >= 512;
-  if (big) {
-    if (split) launch_one<128, 128, true, GLU>(A, W, M, N, K, ep, s);
-    else launch_one<128, 128, false, GLU>(A, W, M, N, K, ep, s);
+const char* launch_sized(const ALoader& A, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep, bool split,
+                         hipStream_t s) {
+  // enough workgroups to fill 256 CUs 1.5x over decides the tile; deep-K small tiles otherwise (latency-bound shapes)
+  if (tiles_of(M, N, 128, 128) >= 384 && K % 64 == 0) {
+    if (split) launch_one<128, 128, 64, true, GLU>(A, W, M, N, K, ep, s);
+    else launch_one<128, 128, 64, false, GLU>(A, W, M, N, K, ep, s);
+  } else if (tiles_of(M, N, 64, 64) >= 384 && K % 128 == 0) {
+    if (split) launch_one<64, 64, 128, true, GLU>(A, W, M, N, K, ep, s);
+    else launch_one<64, 64, 128, false, GLU>(A, W, M, N, K, ep, s);
+  } else if (K % 128 == 0) {
+    constexpr int BN_S = GLU ? 64 : 32;  // the GLU epilogue pairs two 16-column fragments per wave
+    if (split) launch_one<32, BN_S, 128, true, GLU>(A, W, M, N, K, ep, s);
+    else launch_one<32, BN_S, 128, false, GLU>(A, W, M, N, K, ep, s);
+  } else if (K % 32 == 0) {
+    if (split) launch_one<64, 64, 32, true, GLU>(A, W, M, N, K, ep, s);
+    else launch_one<64, 64, 32, false, GLU>(A, W, M, N, K, ep, s);
   } else {
-    if (split) launch_one<64, 64, true, GLU>(A, W, M, N, K, ep, s);
-    else launch_one<64, 64, false, GLU>(A, W, M, N, K, ep, s);
+    return "gemm: K must be a multiple of 32";
   }
+  return nullptr;
 }
 
 }  // namespace
@@ -235,22 +254,32 @@ void launch_sized(const ALoader& A, const uint16_t* W, int M, int N, int K, cons
 const char* launch_gemm(const float* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
                         bool glu, bool split, hipStream_t s) {
   if (M <= 0) return nullptr;
-  if (K % BK != 0) return "gemm: K must be a multiple of 32";
   if (lda % 4 != 0) return "gemm: lda must be a multiple of 4";
   if (glu && N % 32 != 0) return "gemm: GLU needs N % 32 == 0";
   DenseA A{X, lda};
-  if (glu) launch_sized<true>(A, W, M, N, K, ep, split, s);
-  else launch_sized<false>(A, W, M, N, K, ep, split, s);
-  return nullptr;
+  return glu ? launch_sized<true>(A, W, M, N, K, ep, split, s) : launch_sized<false>(A, W, M, N, K, ep, split, s);
 }
 
 const char* launch_conv3x3s2_gemm(const float* X, int imgs, int H, int Wd, int C, const uint16_t* Wt, int Cout,
                                   const GemmEpilogue& ep, bool split, hipStream_t s) {
-  if (C % BK != 0) return "conv gemm: C must be a multiple of 32";
+  if (C % 32 != 0) return "conv gemm: C must be a multiple of 32";
   ConvA A{X, H, Wd, C, (H - 1) / 2 + 1, (Wd - 1) / 2 + 1};
   const int M = imgs * A.OH * A.OW;
   if (M <= 0) return nullptr;
-  launch_sized<false>(A, Wt, M, Cout, 9 * C, ep, split, s);
+  // a K tile must not straddle two filter taps: BK has to divide C
+  if (C % 128 == 0) return launch_sized<false>(A, Wt, M, Cout, 9 * C, ep, split, s);
+  if (C % 64 == 0 && tiles_of(M, Cout, 128, 128) >= 384) {
+    if (split) launch_one<128, 128, 64, true, false>(A, Wt, M, Cout, 9 * C, ep, s);
+    else launch_one<128, 128, 64, false, false>(A, Wt, M, Cout, 9 * C, ep, s);
+    return nullptr;
+  }
+  if (tiles_of(M, Cout, 128, 128) >= 384) {  // C = 480 = 15 x 32: only BK = 32 divides it
+    if (split) launch_one<128, 128, 32, true, false>(A, Wt, M, Cout, 9 * C, ep, s);
+    else launch_one<128, 128, 32, false, false>(A, Wt, M, Cout, 9 * C, ep, s);
+    return nullptr;
+  }
+  if (split) launch_one<64, 64, 32, true, false>(A, Wt, M, Cout, 9 * C, ep, s);
+  else launch_one<64, 64, 32, false, false>(A, Wt, M, Cout, 9 * C, ep, s);
   return nullptr;
 }
 

@@ -1,0 +1,393 @@
+// GEMV family for the single-token decode step on gfx950: y[b][n] = sum_k x[b][k] * W[n][k].
+//
+// Replaces Linear::forward at one token per sequence (src/layers.rs:74-80) with the surrounding
+// RMSNorm (layers.rs:48-54), bias, residual add (layers.rs:442-463) and SiLU(gate)*up (layers.rs:396-400)
+// fused, plus the lm_head matmul + argmax of the greedy loop (src/text_decoder.rs:111-112,
+// src/inference.rs:161).  HBM-bound: every weight byte is streamed exactly once per token, 16 B per lane
+// per load (a wave reads 1 KiB of one weight row per instruction); weights are bf16, x stays fp32, so
+// the products are fp32-exact and only the summation order differs from the reference.
+//
+// Everything in these kernels is latency (a 4-12 MB matrix is 16-48 KB per CU), so the order of work is
+//   1. issue the first PF weight loads of every row the wave owns -- they do not depend on x;
+//   2. fetch x (L2-resident) while those are in flight.  With one sequence (NB == 1) each lane loads
+//      exactly the x slice its weight columns need straight into registers: no LDS, no barrier, and
+//      sum(x^2) for the RMSNorm is a plain wavefront reduction because a wave covers all of K.  For
+//      NB in {2,4} x is staged through LDS once per workgroup;
+//   3. FMA.  The RMSNorm scale is a scalar per row of x, so it multiplies the finished dot product
+//      instead of every element (the reference's (x*rstd)*w differs by fp32 rounding only);
+//   4. wavefront reduction on DPP (no LDS crossbar), fused epilogue.
+// x can also be assembled on the fly from the flash-decoding partials of k_dattn.hip (o_proj input).
+#include "dev.h"
+#include "kernels.h"
+
+namespace q3a {
+
+int gemv_rows_per_wave(const GemvArgs& a) {  // physical weight rows per wave
+  const int logical = (a.mode == 2) ? a.N / 2 : a.N;
+  if (logical >= 32768) return 4;
+  if (logical >= 4096 || a.mode == 2) return 2;
+  return 1;
+}
+int gemv_blocks(const GemvArgs& a) {
+  const int pr = gemv_rows_per_wave(a);
+  const int rows_per_wave = (a.mode == 2) ? pr / 2 : pr;
+  const int logical = (a.mode == 2) ? a.N / 2 : a.N;
+  return (logical + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+}
+
+namespace {
+
+// Flash-decoding merge (o_proj input).  attn_scales: every workgroup first turns the per-split softmax
+// statistics (m, l) of k_dattn.hip into one scale factor per (sequence, head, split),
+// f = exp(m - M) / L, in LDS; attn_combined8 then builds 8 consecutive elements (k .. k+7, inside one head)
+// of the attention output as sum_split f * o_split -- loads that depend on nothing but the partial buffers.
+constexpr int ATTN_F_MAX = 1024;  // NB * heads * nsplit entries (three LDS tables of this size)
+struct AttnTables {
+  float m[ATTN_F_MAX], l[ATTN_F_MAX], f[ATTN_F_MAX];
+};
+__device__ __forceinline__ void attn_scales(const GemvArgs& a, int nb, AttnTables& t) {
+  const int ns = a.attn_nsplit, n = nb * a.attn_heads * ns;
+  // one thread per (sequence, head, split): all statistics are fetched in ONE round of parallel loads
+  for (int i = threadIdx.x; i < n; i += 256) {
+    t.m[i] = a.attn_pm[i];
+    t.l[i] = a.attn_pl[i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int base = (i / ns) * ns;
+    float M = -INFINITY;
+    for (int sp = 0; sp < ns; ++sp) M = fmaxf(M, t.m[base + sp]);
+    float L = 0.f;
+    for (int sp = 0; sp < ns; ++sp) {
+      const float m = t.m[base + sp];
+      if (m != -INFINITY) L += t.l[base + sp] * expf(m - M);
+    }
+    const float mi = t.m[i];
+    t.f[i] = (mi == -INFINITY) ? 0.f : expf(mi - M) / L;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void attn_combined8(const GemvArgs& a, int b, int k, const AttnTables& t, float (&x)[8]) {
+  const int h = k >> 7, d = k & 127;
+  const int ns = a.attn_nsplit;
+  const int base = (b * a.attn_heads + h) * ns;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = 0.f;
+  for (int sp0 = 0; sp0 < ns; sp0 += 4) {  // 4 splits (8 independent 16-B loads) in flight at a time
+    float4 o0[4], o1[4];
+    float f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int sp = sp0 + j, spc = sp < ns ? sp : ns - 1;  // clamp the address, zero the weight
+      f[j] = sp < ns ? t.f[base + spc] : 0.f;
+      o0[j] = *reinterpret_cast<const float4*>(a.attn_po + (size_t)(base + spc) * 128 + d);
+      o1[j] = *reinterpret_cast<const float4*>(a.attn_po + (size_t)(base + spc) * 128 + d + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // empty splits carry f = 0 and zeroed partials
+      x[0] += o0[j].x * f[j]; x[1] += o0[j].y * f[j]; x[2] += o0[j].z * f[j]; x[3] += o0[j].w * f[j];
+      x[4] += o1[j].x * f[j]; x[5] += o1[j].y * f[j]; x[6] += o1[j].z * f[j]; x[7] += o1[j].w * f[j];
+    }
+  }
+}
+
+template <int PR>
+__device__ __forceinline__ void gemv_rows(const GemvArgs& a, int g, int (&prow)[PR]) {
+#pragma unroll
+  for (int i = 0; i < PR; ++i) {
+    if (a.mode == 2) {
+      const int j = g * (PR / 2) + (i >> 1);  // logical row; W rows come in [16 gate | 16 up] blocks
+      prow[i] = (j / 16) * 32 + (j % 16) + ((i & 1) ? 16 : 0);
+    } else {
+      prow[i] = g * PR + i;
+    }
+    if (prow[i] >= a.N) prow[i] = -1;
+  }
+}
+
+__device__ __forceinline__ float dot8(const uint4& w, const float (&x)[8], float s) {
+  s += bf16lo(w.x) * x[0]; s += bf16hi(w.x) * x[1]; s += bf16lo(w.y) * x[2]; s += bf16hi(w.y) * x[3];
+  s += bf16lo(w.z) * x[4]; s += bf16hi(w.z) * x[5]; s += bf16lo(w.w) * x[6]; s += bf16hi(w.w) * x[7];
+  return s;
+}
+
+// epilogue shared by both variants; acc holds the finished (rstd-scaled) dot products, valid on every lane
+template <int NB, int PR>
+__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int g, const int (&prow)[PR], float (&acc)[PR][NB],
+                                              float (*am_v)[NB], int (*am_i)[NB]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (a.mode == 3) {  // logits + argmax partial (first-index tie-break: rows ascend with i, wave, block)
+    float bv[NB];
+    int bi[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { bv[b] = -INFINITY; bi[b] = 0x7fffffff; }
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+      if (prow[i] < 0) continue;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float v = acc[i][b];
+        if (a.bias) v += a.bias[prow[i]];
+        if (lane == 0 && a.out) a.out[(size_t)b * a.ldo + prow[i]] = v;
+        if (v > bv[b]) { bv[b] = v; bi[b] = prow[i]; }
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { am_v[wave][b] = bv[b]; am_i[wave][b] = bi[b]; }
+    }
+    __syncthreads();
+    if (tid < NB) {
+      float v = am_v[0][tid];
+      int ix = am_i[0][tid];
+      for (int w = 1; w < 4; ++w)
+        if (am_v[w][tid] > v || (am_v[w][tid] == v && am_i[w][tid] < ix)) { v = am_v[w][tid]; ix = am_i[w][tid]; }
+      a.part_val[(size_t)tid * a.part_stride + blockIdx.x] = v;
+      a.part_idx[(size_t)tid * a.part_stride + blockIdx.x] = ix;
+    }
+    return;
+  }
+  if (lane != 0) return;
+  if (a.mode != 2) {
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+      if (prow[i] < 0) continue;
+      const int n = prow[i];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float v = acc[i][b];
+        if (a.bias) v += a.bias[n];
+        if (a.mode == 1) v += a.resid[(size_t)b * a.ldo + n];
+        a.out[(size_t)b * a.ldo + n] = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i + 1 < PR; i += 2) {
+      if (prow[i] < 0) continue;
+      const int j = g * (PR / 2) + (i >> 1);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float gv = acc[i][b], uv = acc[i + 1][b];
+        if (a.bias) { gv += a.bias[prow[i]]; uv += a.bias[prow[i + 1]]; }
+        a.out[(size_t)b * a.ldo + j] = silu_f(gv) * uv;
+      }
+    }
+  }
+}
+
+// ---- NB == 1: x lives in registers (KI k-iterations of 512 columns, K <= 512*KI) ---------------------
+template <int PR, int PF, int KI>
+__global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
+  __shared__ float am_v[4][1];
+  __shared__ int am_i[4][1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K;
+  const int g = blockIdx.x * 4 + wave;
+  int prow[PR];
+  gemv_rows<PR>(a, g, prow);
+  // 1. weight prefetch
+  uint4 wq[PF][PR];
+#pragma unroll
+  for (int it = 0; it < PF; ++it) {
+    const int k = lane * 8 + it * 512;
+#pragma unroll
+    for (int i = 0; i < PR; ++i)
+      wq[it][i] = (prow[i] >= 0 && k < K) ? *reinterpret_cast<const uint4*>(a.W + (size_t)prow[i] * K + k)
+                                          : make_uint4(0u, 0u, 0u, 0u);
+  }
+  // 2. this lane's slice of x
+  __shared__ AttnTables f_s;
+  if (a.attn_po) attn_scales(a, 1, f_s);  // wave-uniform branch (kernel argument)
+  float x[KI][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < KI; ++it) {
+    const int k = lane * 8 + it * 512;
+    if (k < K) {
+      if (a.attn_po) {
+        attn_combined8(a, 0, k, f_s, x[it]);
+      } else {
+        const float4 v0 = *reinterpret_cast<const float4*>(a.x + k);
+        const float4 v1 = *reinterpret_cast<const float4*>(a.x + k + 4);
+        x[it][0] = v0.x; x[it][1] = v0.y; x[it][2] = v0.z; x[it][3] = v0.w;
+        x[it][4] = v1.x; x[it][5] = v1.y; x[it][6] = v1.z; x[it][7] = v1.w;
+      }
+      if (a.rms_w) {
+        const float4 w0 = *reinterpret_cast<const float4*>(a.rms_w + k);
+        const float4 w1 = *reinterpret_cast<const float4*>(a.rms_w + k + 4);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ss += x[it][e] * x[it][e]; x[it][e] *= wv[e]; }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[it][e] = 0.f;
+    }
+  }
+  // 3. dot products
+  float acc[PR][1];
+#pragma unroll
+  for (int i = 0; i < PR; ++i) acc[i][0] = 0.f;
+#pragma unroll
+  for (int it = 0; it < KI; ++it) {
+    const int k = lane * 8 + it * 512;
+    if (it < PF) {
+#pragma unroll
+      for (int i = 0; i < PR; ++i) acc[i][0] = dot8(wq[it < PF ? it : 0][i], x[it], acc[i][0]);
+    } else if (k < K) {
+#pragma unroll
+      for (int i = 0; i < PR; ++i) {
+        const uint4 w = prow[i] >= 0 ? *reinterpret_cast<const uint4*>(a.W + (size_t)prow[i] * K + k) : make_uint4(0u, 0u, 0u, 0u);
+        acc[i][0] = dot8(w, x[it], acc[i][0]);
+      }
+    }
+  }
+  float rstd = 1.0f;
+  if (a.rms_w) rstd = 1.0f / sqrtf(wave_sum_fast(ss) / (float)K + a.eps);  // a wave covers all of K
+#pragma unroll
+  for (int i = 0; i < PR; ++i) acc[i][0] = wave_sum_fast(acc[i][0]) * rstd;
+  gemv_epilogue<1, PR>(a, g, prow, acc, am_v, am_i);
+}
+
+// ---- NB in {2, 4}: x staged through LDS once per workgroup ---------------------------------------------
+template <int NB, int PR, int PF>
+__global__ __launch_bounds__(256) void gemvn_kernel(GemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [NB][K]
+  __shared__ float red[NB][4];
+  __shared__ float am_v[4][NB];
+  __shared__ int am_i[4][NB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K;
+  const int g = blockIdx.x * 4 + wave;
+  int prow[PR];
+  gemv_rows<PR>(a, g, prow);
+  uint4 wq[PF][PR];
+#pragma unroll
+  for (int it = 0; it < PF; ++it) {
+    const int k = lane * 8 + it * 512;
+#pragma unroll
+    for (int i = 0; i < PR; ++i)
+      wq[it][i] = (prow[i] >= 0 && k < K) ? *reinterpret_cast<const uint4*>(a.W + (size_t)prow[i] * K + k)
+                                          : make_uint4(0u, 0u, 0u, 0u);
+  }
+  __shared__ AttnTables f_s;
+  if (a.attn_po) attn_scales(a, NB, f_s);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float ss = 0.f;
+    for (int k = tid * 8; k < K; k += 2048) {
+      float x[8];
+      if (a.attn_po) {
+        attn_combined8(a, b, k, f_s, x);
+      } else {
+        const float4 v0 = *reinterpret_cast<const float4*>(a.x + (size_t)b * a.ldx + k);
+        const float4 v1 = *reinterpret_cast<const float4*>(a.x + (size_t)b * a.ldx + k + 4);
+        x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+      }
+      if (a.rms_w) {
+        const float4 w0 = *reinterpret_cast<const float4*>(a.rms_w + k);
+        const float4 w1 = *reinterpret_cast<const float4*>(a.rms_w + k + 4);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ss += x[e] * x[e]; x[e] *= wv[e]; }
+      }
+      *reinterpret_cast<float4*>(xs + (size_t)b * K + k) = make_float4(x[0], x[1], x[2], x[3]);
+      *reinterpret_cast<float4*>(xs + (size_t)b * K + k + 4) = make_float4(x[4], x[5], x[6], x[7]);
+    }
+    if (a.rms_w) {
+      ss = wave_sum_fast(ss);
+      if (lane == 0) red[b][wave] = ss;
+    }
+  }
+  __syncthreads();
+  float acc[PR][NB];
+#pragma unroll
+  for (int i = 0; i < PR; ++i)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[i][b] = 0.f;
+  auto fma_all = [&](const uint4 (&w)[PR], int k) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const float4 xa = *reinterpret_cast<const float4*>(xs + (size_t)b * K + k);
+      const float4 xb = *reinterpret_cast<const float4*>(xs + (size_t)b * K + k + 4);
+      const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+      for (int i = 0; i < PR; ++i) acc[i][b] = dot8(w[i], x, acc[i][b]);
+    }
+  };
+#pragma unroll
+  for (int it = 0; it < PF; ++it) {
+    const int k = lane * 8 + it * 512;
+    if (k < K) fma_all(wq[it], k);
+  }
+  for (int k = lane * 8 + PF * 512; k < K; k += 512) {
+    uint4 w[PR];
+#pragma unroll
+    for (int i = 0; i < PR; ++i)
+      w[i] = prow[i] >= 0 ? *reinterpret_cast<const uint4*>(a.W + (size_t)prow[i] * K + k) : make_uint4(0u, 0u, 0u, 0u);
+    fma_all(w, k);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float rstd = 1.0f;
+    if (a.rms_w) rstd = 1.0f / sqrtf((red[b][0] + red[b][1] + red[b][2] + red[b][3]) / (float)K + a.eps);
+#pragma unroll
+    for (int i = 0; i < PR; ++i) acc[i][b] = wave_sum_fast(acc[i][b]) * rstd;
+  }
+  gemv_epilogue<NB, PR>(a, g, prow, acc, am_v, am_i);
+}
+
+template <int PR, int PF>
+void launch1(const GemvArgs& a, hipStream_t s) {
+  const dim3 grid(gemv_blocks(a)), block(256);
+  if (a.K <= 1024) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 2 ? PF : 2), 2>), grid, block, 0, s, a);
+  else if (a.K <= 2048) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 4 ? PF : 4), 4>), grid, block, 0, s, a);
+  else if (a.K <= 3072) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 6 ? PF : 6), 6>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 12 ? PF : 12), 12>), grid, block, 0, s, a);
+}
+template <int NB, int PR, int PF>
+void launchn(const GemvArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((gemvn_kernel<NB, PR, PF>), dim3(gemv_blocks(a)), dim3(256), (size_t)NB * a.K * sizeof(float), s, a);
+}
+
+}  // namespace
+
+const char* launch_gemv(const GemvArgs& a0, int NB, hipStream_t s) {
+  if (a0.K % 8 != 0) return "gemv: K must be a multiple of 8";
+  if (a0.K > 6144) return "gemv: K > 6144 unsupported";
+  if (a0.mode == 2 && a0.N % 32 != 0) return "gemv: GLU needs N % 32 == 0";
+  if (a0.mode == 3 && (!a0.part_val || !a0.part_idx || gemv_blocks(a0) > a0.part_stride))
+    return "gemv: argmax partial buffer missing/too small";
+  if (a0.attn_po && (a0.K % 128 != 0 || a0.K != a0.attn_heads * 128)) return "gemv: attention-partial input needs K = heads*128";
+  if (a0.attn_po && (NB < 4 ? NB : 4) * a0.attn_heads * a0.attn_nsplit > ATTN_F_MAX) return "gemv: too many attention splits for the LDS scale table";
+  const int pr = gemv_rows_per_wave(a0);
+  const int nb_cap = (int)((64 * 1024) / ((size_t)a0.K * 4));  // rows of x that fit in 64 KiB of LDS
+  int done = 0;
+  while (done < NB) {
+    GemvArgs a = a0;
+    if (a0.x) a.x = a0.x + (size_t)done * a0.ldx;
+    if (a0.out) a.out = a0.out + (size_t)done * a0.ldo;
+    if (a0.resid) a.resid = a0.resid + (size_t)done * a0.ldo;
+    if (a0.part_val) { a.part_val = a0.part_val + (size_t)done * a0.part_stride; a.part_idx = a0.part_idx + (size_t)done * a0.part_stride; }
+    if (a0.attn_po) {
+      const size_t adv = (size_t)done * a0.attn_heads * a0.attn_nsplit;
+      a.attn_pm = a0.attn_pm + adv; a.attn_pl = a0.attn_pl + adv; a.attn_po = a0.attn_po + adv * 128;
+    }
+    int nb = NB - done;
+    if (nb >= 4 && nb_cap >= 4) nb = 4;
+    else if (nb >= 2 && nb_cap >= 2) nb = 2;
+    else nb = 1;
+    if (nb == 1) {
+      if (pr == 4) launch1<4, 2>(a, s); else if (pr == 2) launch1<2, 4>(a, s); else launch1<1, 12>(a, s);
+    } else if (nb == 2) {
+      if (pr == 4) launchn<2, 4, 2>(a, s); else if (pr == 2) launchn<2, 2, 4>(a, s); else launchn<2, 1, 6>(a, s);
+    } else {
+      if (pr == 4) launchn<4, 4, 2>(a, s); else if (pr == 2) launchn<4, 2, 4>(a, s); else launchn<4, 1, 6>(a, s);
+    }
+    done += nb;
+  }
+  return nullptr;
+}
+
+}  // namespace q3a

@@ -105,8 +105,12 @@ struct GemvArgs {
   float* out; int ldo;
   const float* resid;
   float* part_val; int* part_idx; int part_stride;  // mode 3: [NB][part_stride], entry = blockIdx.x
+  // optional: x = attention output merged on the fly from the flash-decoding partials of launch_decode_attn
+  // (x/ldx ignored; K must equal attn_heads*128)
+  const float* attn_pm; const float* attn_pl; const float* attn_po; int attn_nsplit; int attn_heads;
 };
 const char* launch_gemv(const GemvArgs& a, int NB, hipStream_t s);
+constexpr int GEMV_ATTN_MAX_TABLE = 1024;  // min(NB,4) * heads * nsplit must fit (else merge with launch_attn_combine first)
 int gemv_blocks(const GemvArgs& a);        // grid size launch_gemv uses (= number of argmax partials in mode 3)
 int gemv_rows_per_wave(const GemvArgs& a);
 
@@ -116,11 +120,18 @@ struct DecodeAttnArgs {
   const float* q_norm; const float* k_norm; float eps;
   const float* cos_t; const float* sin_t;
   void* kcache; void* vcache;  // this layer
-  float* out;                  // [S][n_q*128]
+  float* pm; float* pl;        // [S][n_q][nsplit] partial softmax max / sum per key split
+  float* po;                   // [S][n_q][nsplit][128] unnormalised partial outputs
+  int nsplit;                  // >= ceil(max_ctx / dattn_keys_per_split(kv_f32))
   int n_q, n_kv, max_ctx;
   float scale_div;
 };
+constexpr int DATTN_KEYS_PER_SPLIT_BF16 = 128, DATTN_KEYS_PER_SPLIT_F32 = 128;
+inline int dattn_keys_per_split(bool kv_f32) { return kv_f32 ? DATTN_KEYS_PER_SPLIT_F32 : DATTN_KEYS_PER_SPLIT_BF16; }
 const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
+// out[S][n_q*128] = merged partials (needed as its own launch only on the GEMM decode path)
+const char* launch_attn_combine(const float* pm, const float* pl, const float* po, int nsplit, int S, int n_q, float* out,
+                                hipStream_t s);
 
 struct FinalizeArgs {
   const float* part_val;   // [S][part_stride] block-partial maxima ...
