@@ -33,7 +33,9 @@ typedef struct q3a_opts {
   int32_t max_new_tokens; /* generation cap per utterance (reference: 4096, src/inference.rs:153); 0 -> 4096 */
   int32_t use_graph;      /* 1: replay the decode step from a captured hipGraph (default 1 when 0/unset -> see q3a_opts_default) */
   int32_t debug_taps;     /* 1: keep per-stage intermediate tensors readable through q3a_debug_read      */
-  int32_t reserved[12];
+  int32_t valu_attention; /* 1: use the fp32 VALU attention kernels in default mode too (A/B against the
+                             MFMA flash-attention kernels; precise mode always uses them)                 */
+  int32_t reserved[11];
 } q3a_opts;
 
 /* Fill `o` with the defaults (precise=0, max_new_tokens=4096, use_graph=1, debug_taps=0). */

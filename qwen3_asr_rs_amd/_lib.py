@@ -20,7 +20,7 @@ SYMBOLS = [
 
 class Opts(C.Structure):
     _fields_ = [("precise", C.c_int32), ("max_new_tokens", C.c_int32), ("use_graph", C.c_int32),
-                ("debug_taps", C.c_int32), ("reserved", C.c_int32 * 12)]
+                ("debug_taps", C.c_int32), ("valu_attention", C.c_int32), ("reserved", C.c_int32 * 11)]
 
 
 class DimsC(C.Structure):

@@ -357,7 +357,7 @@ struct q3a_engine {
         GemmEpilogue ep; ep.out = enc_qkv.as<float>(); ep.ldo = 3 * D; ep.bias = wf(e.qkv_b);
         KCHK(launch_gemm(enc_ln.as<float>(), D, wh(e.qkv_w), total_T, 3 * D, D, ep, false, sp, stream));
       }
-      KCHK(launch_attn_enc(at, stream));
+      if (sp || opts.valu_attention) KCHK(launch_attn_enc(at, stream)); else KCHK(launch_fattn_enc(at, stream));
       {
         GemmEpilogue ep; ep.out = enc_x.as<float>(); ep.ldo = D; ep.bias = wf(e.out_b); ep.resid = enc_x.as<float>();
         KCHK(launch_gemm(enc_ctx.as<float>(), D, wh(e.out_w), total_T, D, D, ep, false, sp, stream));
@@ -510,7 +510,7 @@ struct q3a_engine {
       rk.kcache = kc_layer(li); rk.vcache = vc_layer(li); rk.n_q = d.n_q; rk.n_kv = d.n_kv; rk.max_ctx = max_ctx;
       KCHK(launch_qknorm_rope_kv(rk, total_P, kv_f32(), stream));
       at.k = kc_layer(li); at.v = vc_layer(li);
-      KCHK(launch_attn_prefill(at, d.n_q / d.n_kv, kv_f32(), stream));
+      if (kv_f32() || opts.valu_attention) KCHK(launch_attn_prefill(at, d.n_q / d.n_kv, kv_f32(), stream)); else KCHK(launch_fattn_prefill(at, d.n_q / d.n_kv, stream));
       {
         GemmEpilogue ep; ep.out = dec_x.as<float>(); ep.ldo = H; ep.resid = dec_x.as<float>(); ep.bias = o_bias ? wf(l.o_b) : nullptr;
         KCHK(launch_gemm(dec_ctx.as<float>(), QD, wh(l.o_w), total_P, H, QD, ep, false, sp, stream));

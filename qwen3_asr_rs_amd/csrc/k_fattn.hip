@@ -1,0 +1,235 @@
+// MFMA flash attention over independent segments for gfx950 (default bf16 mode; the fp32 VALU kernel of
+// k_attn.hip remains the precise-mode path and the on-device reference).
+//
+// Same contract as k_attn.hip (AttnArgs / AttnSeg): encoder window attention (src/layers.rs:152-172 with the
+// block-diagonal mask of src/audio_encoder.rs:172-260 turned into segments) and the causal GQA prefill attention
+// of src/layers.rs:321-335.
+//
+// Workgroup = 4 waves = (4/GROUP) tiles of 32 queries x GROUP query heads sharing one K/V head.  Per 32-key tile:
+//   * the block stages K[32][HD] (bf16, rows padded by 16 B) and V^T[HD][32] (bf16) in LDS; the next tile's
+//     global loads are already in flight in registers while the current one is consumed;
+//   * S^T = K . Q^T on v_mfma_f32_32x32x16_bf16 ("swapped" product): a lane then owns ONE query column
+//     (lane&31) and 16 of the 32 keys, so the online-softmax statistics are register-local plus one exchange with
+//     lane^32, and the rescale factor of the running output is lane-local as well;
+//   * P^T is packed to bf16 in registers and fed straight back as the B operand of O^T += V^T . P^T -- the
+//     contraction index is permuted so that each lane's own 8 P values per k-step are exactly its B fragment;
+//     the matching V^T fragment is two 8-byte LDS reads.
+// Scores are divided by sqrt(hd) after the product as the reference does.  Q and P enter the MFMA as bf16, K/V
+// are the bf16 cache (or fp32 projections rounded while staging): same rounding class as every other bf16 GEMM
+// operand of the default mode.
+#include "dev.h"
+#include "kernels.h"
+
+namespace q3a {
+namespace {
+
+constexpr int KT = 32;  // keys per tile
+
+template <typename KVT> struct Stage8;  // 8 consecutive head dims of one K/V row -> 8 packed bf16
+template <> struct Stage8<uint16_t> {
+  static __device__ __forceinline__ uint4 load(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+};
+template <> struct Stage8<float> {
+  static __device__ __forceinline__ uint4 load(const float* p) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    uint4 r;
+    r.x = pack_bf16x2(a.x, a.y); r.y = pack_bf16x2(a.z, a.w); r.z = pack_bf16x2(b.x, b.y); r.w = pack_bf16x2(b.z, b.w);
+    return r;
+  }
+};
+
+template <int HD, int GROUP, bool CAUSAL, typename KVT>
+__global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
+  constexpr int QTILES = 4 / GROUP;          // 32-query tiles per block
+  constexpr int QT = 32 * QTILES;            // queries per block
+  constexpr int KS = HD / 16;                // MFMA k-steps of the QK^T product
+  constexpr int DT = HD / 32;                // 32-row tiles of O^T
+  constexpr int K_STRIDE = HD + 8;           // bf16 per K row in LDS (16 B pad)
+  constexpr int V_STRIDE = KT + 8;           // bf16 per V^T row in LDS
+  constexpr int CPR = HD / 8;                // 16-B chunks per K/V row
+  constexpr int LOADS = KT * CPR / 256;      // chunks per thread per tile (HD=128: 2, HD=64: 1)
+  static_assert(LOADS >= 1, "tile too small");
+  __shared__ __attribute__((aligned(16))) uint16_t k_lds[KT * K_STRIDE];
+  __shared__ __attribute__((aligned(16))) uint16_t vt_lds[HD * V_STRIDE];
+
+  const AttnSeg seg = a.segs[blockIdx.z];
+  const int kvh = blockIdx.y;
+  const int qb0 = blockIdx.x * QT;
+  if (qb0 >= seg.len) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int g = wave % GROUP, qs = wave / GROUP;
+  const int head = kvh * GROUP + g;
+  const int q0 = qb0 + qs * 32;              // first query of this wave
+  const int qi = q0 + l31;                   // this lane's query (both halves of the wave hold the same 32 queries)
+  const bool wave_has_q = q0 < seg.len;
+  const KVT* kbase = reinterpret_cast<const KVT*>(a.k) + seg.kv_off + (int64_t)kvh * a.kv_hs;
+  const KVT* vbase = reinterpret_cast<const KVT*>(a.v) + seg.kv_off + (int64_t)kvh * a.kv_hs;
+
+  // ---- Q^T fragments (B operand): lane holds Q[qi][ks*16 + half*8 .. +8] as bf16 ----
+  bf16x8_t qfrag[KS];
+  {
+    const float* qrow = a.q + (size_t)(seg.q_row0 + (qi < seg.len ? qi : seg.len - 1)) * a.q_rs + head * HD;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 x0 = *reinterpret_cast<const float4*>(qrow + ks * 16 + half * 8);
+      const float4 x1 = *reinterpret_cast<const float4*>(qrow + ks * 16 + half * 8 + 4);
+      uint4 p;
+      p.x = pack_bf16x2(x0.x, x0.y); p.y = pack_bf16x2(x0.z, x0.w); p.z = pack_bf16x2(x1.x, x1.y); p.w = pack_bf16x2(x1.z, x1.w);
+      qfrag[ks] = *reinterpret_cast<const bf16x8_t*>(&p);
+    }
+  }
+  f32x16_t oacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+
+  const int block_qmax = min(qb0 + QT, seg.len) - 1;
+  const int n_keys = CAUSAL ? block_qmax + 1 : seg.len;
+  const int n_tiles = (n_keys + KT - 1) / KT;
+  const int wave_qmax = min(q0 + 32, seg.len) - 1;
+
+  // staging assignment: chunk c of the tile = (row c / CPR, 8 dims (c % CPR)*8)
+  uint4 kreg[LOADS], vreg[LOADS];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int c = tid + i * 256, row = c / CPR, d0 = (c % CPR) * 8;
+      const int key = t * KT + row;
+      if (key < seg.len) {
+        kreg[i] = Stage8<KVT>::load(kbase + (int64_t)key * a.kv_rs + d0);
+        vreg[i] = Stage8<KVT>::load(vbase + (int64_t)key * a.kv_rs + d0);
+      } else {
+        kreg[i] = make_uint4(0u, 0u, 0u, 0u);
+        vreg[i] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      const int c = tid + i * 256, row = c / CPR, d0 = (c % CPR) * 8;
+      *reinterpret_cast<uint4*>(&k_lds[row * K_STRIDE + d0]) = kreg[i];
+      const uint32_t w[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // transpose: V^T[d][key]
+        vt_lds[(d0 + 2 * e) * V_STRIDE + row] = (uint16_t)(w[e] & 0xffffu);
+        vt_lds[(d0 + 2 * e + 1) * V_STRIDE + row] = (uint16_t)(w[e] >> 16);
+      }
+    }
+  };
+
+  load_tile(0);
+  for (int t = 0; t < n_tiles; ++t) {
+    __syncthreads();  // every wave is done with the previous tile
+    store_tile();
+    __syncthreads();
+    if (t + 1 < n_tiles) load_tile(t + 1);
+    const int key0 = t * KT;
+    if (!wave_has_q || (CAUSAL && key0 > wave_qmax)) continue;
+
+    // ---- S^T[key][query] = sum_d K[key][d] Q[query][d] ----
+    f32x16_t sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&k_lds[l31 * K_STRIDE + ks * 16 + half * 8]);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfrag[ks], sacc, 0, 0, 0);
+    }
+    // lane owns query qi and keys key0 + (r&3) + 8*(r>>2) + 4*half
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const bool valid = key < seg.len && (!CAUSAL || key <= qi);
+      sacc[r] = valid ? sacc[r] / a.scale_div : -INFINITY;
+      tmax = fmaxf(tmax, sacc[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(mrun, tmax);
+    float alpha = 1.f, psum = 0.f;
+    if (m_new == -INFINITY) {  // nothing visible yet for this query (only for padding queries)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    } else {
+      alpha = expf(mrun - m_new);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sacc[r] = expf(sacc[r] - m_new);  // exp(-inf) = 0 for masked keys
+        psum += sacc[r];
+      }
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    lrun = lrun * alpha + psum;
+    mrun = m_new;
+    // ---- P^T fragments: k-step kk uses this lane's registers kk*8 .. kk*8+7 ----
+    bf16x8_t pfrag[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 p;
+      p.x = pack_bf16x2(sacc[kk * 8 + 0], sacc[kk * 8 + 1]); p.y = pack_bf16x2(sacc[kk * 8 + 2], sacc[kk * 8 + 3]);
+      p.z = pack_bf16x2(sacc[kk * 8 + 4], sacc[kk * 8 + 5]); p.w = pack_bf16x2(sacc[kk * 8 + 6], sacc[kk * 8 + 7]);
+      pfrag[kk] = *reinterpret_cast<const bf16x8_t*>(&p);
+    }
+    // ---- O^T[d][query] = alpha * O^T + sum_key V[key][d] P[key][query] ----
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        // contraction slot (half, e) <-> key 16*kk + 4*half + (e & 3) + 8*(e >> 2): same map as the P registers
+        const uint16_t* vp = &vt_lds[(dt * 32 + l31) * V_STRIDE + 16 * kk + 4 * half];
+        const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vp + 8);
+        uint4 v;
+        v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&v), pfrag[kk], oacc[dt], 0, 0, 0);
+      }
+    }
+  }
+  // ---- write O[query][d] = O^T / l ----
+  if (wave_has_q && qi < seg.len) {
+    const float inv = 1.0f / lrun;
+    float* orow = a.o + (size_t)(seg.q_row0 + qi) * a.o_rs + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {  // registers 4*r4 .. 4*r4+3 are 4 consecutive head dims
+        const int d = dt * 32 + 8 * r4 + 4 * half;
+        *reinterpret_cast<float4*>(orow + d) =
+            make_float4(oacc[dt][4 * r4] * inv, oacc[dt][4 * r4 + 1] * inv, oacc[dt][4 * r4 + 2] * inv, oacc[dt][4 * r4 + 3] * inv);
+      }
+  }
+}
+
+template <int HD, int GROUP, bool CAUSAL, typename KVT>
+void launch_f(const AttnArgs& a, hipStream_t s) {
+  constexpr int QT = 32 * (4 / GROUP);
+  dim3 grid((a.max_len + QT - 1) / QT, a.n_kv_heads, a.n_segs);
+  hipLaunchKernelGGL((fattn_kernel<HD, GROUP, CAUSAL, KVT>), grid, dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+const char* launch_fattn_enc(const AttnArgs& a, hipStream_t s) {
+  if (a.n_segs <= 0) return nullptr;
+  if (a.q_rs % 4 != 0 || a.kv_rs % 4 != 0 || a.o_rs % 4 != 0) return "fattn: row strides must be multiples of 4";
+  launch_f<64, 1, false, float>(a, s);
+  return nullptr;
+}
+
+const char* launch_fattn_prefill(const AttnArgs& a, int group, hipStream_t s) {
+  if (a.n_segs <= 0) return nullptr;
+  if (a.q_rs % 4 != 0 || a.o_rs % 4 != 0) return "fattn: row strides must be multiples of 4";
+  if (group == 1) launch_f<128, 1, true, uint16_t>(a, s);
+  else if (group == 2) launch_f<128, 2, true, uint16_t>(a, s);
+  else if (group == 4) launch_f<128, 4, true, uint16_t>(a, s);
+  else return "fattn: GQA group must be 1, 2 or 4";
+  return nullptr;
+}
+
+}  // namespace q3a

@@ -74,6 +74,9 @@ struct AttnArgs {
 };
 const char* launch_attn_enc(const AttnArgs& a, hipStream_t s);                            // HD=64, 1 q-head per kv head, non-causal, fp32 K/V
 const char* launch_attn_prefill(const AttnArgs& a, int group, bool kv_f32, hipStream_t s);  // HD=128, causal, GQA group 1/2/4
+// MFMA flash-attention versions of the two above (k_fattn.hip): bf16 operands, default mode only
+const char* launch_fattn_enc(const AttnArgs& a, hipStream_t s);                 // fp32 K/V rounded to bf16 while staging
+const char* launch_fattn_prefill(const AttnArgs& a, int group, hipStream_t s);  // bf16 KV cache
 
 // ---- decoder glue (k_decode.hip) ----------------------------------------------------------------------------
 // hidden[r] = embed[ids[r]] for rows whose id is not `skip_id` (audio rows are written by the encoder tail)

@@ -43,7 +43,8 @@ class HipEngine:
     """Thin RAII wrapper of a q3a_engine handle (one per GPU, one host thread per handle)."""
 
     def __init__(self, model_dir: str, device: int = 0, precise: bool = False, max_new_tokens: int = 4096,
-                 use_graph: bool = True, debug_taps: bool = False, device_arena: Optional[Tuple[int, int]] = None):
+                 use_graph: bool = True, debug_taps: bool = False, device_arena: Optional[Tuple[int, int]] = None,
+                 valu_attention: bool = False):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         opts = _lib.Opts()
@@ -52,6 +53,7 @@ class HipEngine:
         opts.max_new_tokens = int(max_new_tokens)
         opts.use_graph = int(use_graph)
         opts.debug_taps = int(debug_taps)
+        opts.valu_attention = int(valu_attention)
         md = os.fsencode(model_dir)
         if device_arena is None:
             rc = self._lib.q3a_engine_create(md, device, C.byref(opts), C.byref(self._h))

@@ -124,6 +124,23 @@ def test_batch_above_gemv_path(tiny_dir):
     _stage_check(tiny_dir, clips, True, steps=3)
 
 
+def test_mfma_attention_matches_valu_attention(tiny_dir):
+    """Default mode: the MFMA flash-attention kernels against the fp32 VALU kernels on the same inputs
+    (two windows in the encoder, ragged causal prefill)."""
+    clips = [synthetic.synthetic_clip(0, 9.3), synthetic.synthetic_clip(1, 2.17)]
+    outs = []
+    for valu in (False, True):
+        eng = HipEngine(tiny_dir, 0, valu_attention=valu, debug_taps=True, max_new_tokens=8)
+        eng.mel(clips)
+        emb = np.concatenate([e.ravel() for e in eng.encode()])
+        prompts = [HipEngine.build_prompt(eng.num_audio_tokens(len(c))) for c in clips]
+        logits, _ = eng.prefill(prompts)
+        outs.append((emb, eng.debug_read("dec_layer0"), logits.ravel()))
+        eng.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert rel_l2(a, b) <= 1e-2
+
+
 def test_graph_replay_equals_eager(tiny_dir):
     clip = synthetic.synthetic_clip(4, 3.0)
     out = []
