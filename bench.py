@@ -125,14 +125,28 @@ def main():
         elapsed = float(t.item())
     stage = eng.timings()
     prof = eng.profile_decode_step()  # per-launch HIP events on the engine's stream, one eager decode step
+    # dominant kernel (largest share of kernel time in the rocprofv3 trace): the qkv / gate-up GEMV instance.
+    # Timed live with ONE HIP event pair around back-to-back launches that sweep all layers' matrices.
+    stream_prof = eng.profile_weight_stream(reps=4) if B <= 4 else None
 
     if rank == 0:
         audio_seconds = world * B * args.seconds * args.steps
-        g = prof["gemv"] if prof["gemv"]["launches"] else prof["gemm"]
-        kname = "gemv_kernel (decode weight streaming)" if prof["gemv"]["launches"] else "gemm_kernel (decode, batched)"
-        bytes_per_launch = g["weight_bytes"] / max(g["launches"], 1)
-        avg_us = g["total_us"] / max(g["launches"], 1)
+        if stream_prof is not None:
+            kname = "gemv1_kernel<2,2,2> (decode qkv + gate/up GEMV: RMSNorm + weight streaming [+SwiGLU])"
+            bytes_per_launch, avg_us, n_launch = stream_prof["bytes_per_launch"], stream_prof["avg_us"], 56
+        else:
+            g = prof["gemm"]
+            kname = "gemm_kernel (batched decode projections)"
+            bytes_per_launch = g["weight_bytes"] / max(g["launches"], 1)
+            avg_us, n_launch = g["total_us"] / max(g["launches"], 1), g["launches"]
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")  # rocprofv3 --pmc passes, see DESIGN.md section 6
+        if stream_prof is not None and args.preset == "0.6b" and os.path.exists(pmc_file):
+            try:
+                traffic = json.load(open(pmc_file))["gemv1_kernel<2, 2, 2>"]["hbm_bytes_per_launch"]
+            except Exception:  # noqa: BLE001
+                traffic = None
         out = {
             "metric": "audio-seconds/sec (RTFx) Qwen3-ASR-0.6B greedy, 30s clips" if args.preset == "0.6b"
                       else f"audio-seconds/sec (RTFx) Qwen3-ASR-{args.preset} greedy, 30s clips",
@@ -148,11 +162,13 @@ def main():
                        "clips_per_gpu": B, "clip_seconds": args.seconds, "new_tokens": args.new_tokens,
                        "parallelism": f"dp{world} (independent utterances per GPU, no data-path collective)"},
             "stage_ms": {k: round(float(v), 3) for k, v in stage.items() if k.endswith("_ms")},
-            "decode_step_profile_us": {k: round(v["total_us"], 1) for k, v in prof.items() if v["launches"]},
+            "decode_step_profile": {k: {"launches": v["launches"], "us_per_launch_evt": round(v["total_us"] / v["launches"], 2),
+                                        "GBps_evt": round(v["weight_bytes"] / max(v["total_us"], 1e-9) / 1e3, 1) if v["weight_bytes"] else None}
+                                    for k, v in prof.items() if v["launches"]},
             "roofline": {"kernel": kname, "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                          "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_us, 3),
-                         "launches_per_token": g["launches"]},
+                         "launches_per_token": n_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

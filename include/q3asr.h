@@ -143,14 +143,22 @@ int32_t q3a_stage_timings(const q3a_engine* e, q3a_timings* out);
 /* Per-kernel-class timing of ONE decode step, each launch bracketed by hipEvents on the engine's
  * stream (eager, not graph).  Requires a batch in decode state (after q3a_run_resident/q3a_prefill).
  * class ids: see Q3A_KC_* ; arrays have Q3A_KC_COUNT entries. */
-enum { Q3A_KC_GEMV = 0, Q3A_KC_DECODE_ATTN = 1, Q3A_KC_ARGMAX = 2, Q3A_KC_GEMM = 3, Q3A_KC_NORM = 4,
-       Q3A_KC_OTHER = 5, Q3A_KC_COUNT = 6 };
+enum { Q3A_KC_GEMV = 0 /* qkv and gate/up GEMVs (2 weight rows per wave) */, Q3A_KC_DECODE_ATTN = 1, Q3A_KC_ARGMAX = 2,
+       Q3A_KC_GEMM = 3, Q3A_KC_NORM = 4, Q3A_KC_OTHER = 5, Q3A_KC_GEMV_O = 6, Q3A_KC_GEMV_DOWN = 7,
+       Q3A_KC_GEMV_LM_HEAD = 8, Q3A_KC_COUNT = 9 };
 typedef struct q3a_kernel_profile {
   float total_us[Q3A_KC_COUNT];
   int32_t launches[Q3A_KC_COUNT];
   double weight_bytes[Q3A_KC_COUNT]; /* algorithmic weight bytes streamed by the class in the step */
 } q3a_kernel_profile;
 int32_t q3a_profile_decode_step(q3a_engine* e, q3a_kernel_profile* out);
+
+/* Back-to-back timing of the dominant decode kernel (the qkv and gate/up GEMVs, gemv1_kernel<2,..>): `reps`
+ * sweeps over ALL decoder layers' qkv and gate/up matrices (0.59 GB at 0.6B, larger than the 256 MB
+ * Infinity Cache, so every launch streams from HBM as in a real step) between ONE pair of HIP events on the
+ * engine's stream.  avg_us = elapsed / launches; bytes_per_launch = algorithmic weight bytes per launch.
+ * Needs decode state with <= 4 sequences; does not change it. */
+int32_t q3a_profile_weight_stream(q3a_engine* e, int32_t reps, float* avg_us, double* bytes_per_launch, int32_t* launches);
 
 /* Debug taps (opts.debug_taps=1): copy a named intermediate to host. `bytes` = capacity of dst;
  * *actual receives the tap size. Names: mel conv1 conv2 conv3 enc_in enc_layer0 enc_last

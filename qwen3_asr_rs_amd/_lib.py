@@ -14,7 +14,7 @@ SYMBOLS = [
     "q3a_engine_destroy", "q3a_last_error", "q3a_get_dims", "q3a_num_frames", "q3a_num_audio_tokens",
     "q3a_build_prompt", "q3a_mel", "q3a_encode", "q3a_prefill", "q3a_decode_step", "q3a_set_next_tokens",
     "q3a_upload_pcm", "q3a_run_resident", "q3a_fetch_ids", "q3a_transcribe_batch", "q3a_stage_timings",
-    "q3a_profile_decode_step", "q3a_debug_read", "q3a_selftest_gemm",
+    "q3a_profile_decode_step", "q3a_profile_weight_stream", "q3a_debug_read", "q3a_selftest_gemm",
 ]
 
 
@@ -37,11 +37,11 @@ class Timings(C.Structure):
                 ("total_audio_tokens", C.c_int32), ("total_prompt_tokens", C.c_int32)]
 
 
-KC_NAMES = ["gemv", "decode_attn", "argmax", "gemm", "norm", "other"]
+KC_NAMES = ["gemv_qkv_gateup", "decode_attn", "argmax", "gemm", "norm", "other", "gemv_o_proj", "gemv_down", "gemv_lm_head"]
 
 
 class KernelProfile(C.Structure):
-    _fields_ = [("total_us", C.c_float * 6), ("launches", C.c_int32 * 6), ("weight_bytes", C.c_double * 6)]
+    _fields_ = [("total_us", C.c_float * 9), ("launches", C.c_int32 * 9), ("weight_bytes", C.c_double * 9)]
 
 
 _lib = None
@@ -81,6 +81,7 @@ def load() -> C.CDLL:
         "q3a_transcribe_batch": (i32, [P, f32p, i64p, i32, i32p, i32, i32, i32, i32p, i32, i32p]),
         "q3a_stage_timings": (i32, [P, C.POINTER(Timings)]),
         "q3a_profile_decode_step": (i32, [P, C.POINTER(KernelProfile)]),
+        "q3a_profile_weight_stream": (i32, [P, i32, f32p, C.POINTER(C.c_double), i32p]),
         "q3a_debug_read": (i32, [P, C.c_char_p, P, u64, C.POINTER(u64)]),
         "q3a_selftest_gemm": (i32, [i32, i32, i32, i32, i32, f32p, f32p]),
     }

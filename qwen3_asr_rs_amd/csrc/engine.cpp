@@ -467,7 +467,7 @@ struct q3a_engine {
       g.W = wh(L.lm_head); g.N = V; g.K = H; g.mode = 3; g.out = logits.as<float>(); g.ldo = V;
       g.part_val = part_val.as<float>(); g.part_idx = part_idx.as<int>(); g.part_stride = part_stride;
       n_part = gemv_blocks(g);
-      timed(Q3A_KC_GEMV, wbytes, [&] { KCHK(launch_gemv(g, S, stream)); });
+      timed(Q3A_KC_GEMV_LM_HEAD, wbytes, [&] { KCHK(launch_gemv(g, S, stream)); });
     } else {
       timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(L.final_norm), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
       GemmEpilogue ep; ep.out = logits.as<float>(); ep.ldo = V;
@@ -573,7 +573,7 @@ struct q3a_engine {
         }
         g.ldx = QD; g.W = wh(l.o_w); g.N = H; g.K = QD; g.bias = o_bias ? wf(l.o_b) : nullptr;
         g.mode = 1; g.out = x_dec.as<float>(); g.ldo = H; g.resid = x_dec.as<float>();
-        timed(Q3A_KC_GEMV, 2.0 * H * QD, [&] { KCHK(launch_gemv(g, S, stream)); });
+        timed(Q3A_KC_GEMV_O, 2.0 * H * QD, [&] { KCHK(launch_gemv(g, S, stream)); });
         GemvArgs u{};
         u.x = x_dec.as<float>(); u.ldx = H; u.rms_w = wf(l.post_ln); u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
         u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act.as<float>(); u.ldo = I;
@@ -581,7 +581,7 @@ struct q3a_engine {
         GemvArgs dn{};
         dn.x = s_act.as<float>(); dn.ldx = I; dn.W = wh(l.down_w); dn.N = H; dn.K = I; dn.bias = mlp_bias ? wf(l.down_b) : nullptr;
         dn.mode = 1; dn.out = x_dec.as<float>(); dn.ldo = H; dn.resid = x_dec.as<float>();
-        timed(Q3A_KC_GEMV, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, stream)); });
+        timed(Q3A_KC_GEMV_DOWN, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, stream)); });
       } else {
         const bool sp = precise();
         timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream)); });
@@ -1008,6 +1008,48 @@ int32_t q3a_profile_decode_step(q3a_engine* e, q3a_kernel_profile* out) {
     (void)hipEventDestroy(pe.a);
     (void)hipEventDestroy(pe.b);
   }
+  Q3A_CATCH(e)
+}
+
+int32_t q3a_profile_weight_stream(q3a_engine* e, int32_t reps, float* avg_us, double* bytes_per_launch, int32_t* launches) {
+  if (!e) return 1;
+  Q3A_TRY(e)
+  HIPCHK(hipSetDevice(e->device));
+  if (!e->have_prefill) fail("q3a_profile_weight_stream: no decode state");
+  if (e->B > 4) fail("q3a_profile_weight_stream: the GEMV path serves at most 4 sequences");
+  if (reps < 1) reps = 1;
+  const Dims& d = e->d;
+  const int S = e->B, H = d.hidden, I = d.inter, QKV = d.qkv_dim();
+  auto sweep = [&]() {
+    for (int li = 0; li < d.dec_layers; ++li) {
+      const DecLayerOff& l = e->L.dec[li];
+      GemvArgs g{};
+      g.x = e->x_dec.as<float>(); g.ldx = H; g.rms_w = e->wf(l.in_ln); g.eps = d.rms_eps; g.W = e->wh(l.qkv_w); g.N = QKV; g.K = H;
+      g.mode = 0; g.out = e->s_qkv.as<float>(); g.ldo = QKV;
+      KCHK(launch_gemv(g, S, e->stream));
+      GemvArgs u{};
+      u.x = e->x_dec.as<float>(); u.ldx = H; u.rms_w = e->wf(l.post_ln); u.eps = d.rms_eps; u.W = e->wh(l.gu_w); u.N = 2 * I; u.K = H;
+      u.mode = 2; u.out = e->s_act.as<float>(); u.ldo = I;
+      KCHK(launch_gemv(u, S, e->stream));
+    }
+  };
+  sweep();  // warm-up (code objects, clocks)
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a));
+  HIPCHK(hipEventCreate(&b));
+  HIPCHK(hipEventRecord(a, e->stream));
+  for (int r = 0; r < reps; ++r) sweep();
+  HIPCHK(hipEventRecord(b, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  const int n = reps * d.dec_layers * 2;
+  if (avg_us) *avg_us = ms * 1000.f / (float)n;
+  if (bytes_per_launch) *bytes_per_launch = (2.0 * QKV * H + 4.0 * I * H) / 2.0;
+  if (launches) *launches = n;
   Q3A_CATCH(e)
 }
 

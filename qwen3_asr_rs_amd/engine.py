@@ -190,6 +190,12 @@ class HipEngine:
         return {name: {"total_us": float(p.total_us[i]), "launches": int(p.launches[i]), "weight_bytes": float(p.weight_bytes[i])}
                 for i, name in enumerate(_lib.KC_NAMES)}
 
+    def profile_weight_stream(self, reps: int = 4) -> dict:
+        """Back-to-back qkv + gate/up GEMVs over all layers between one HIP event pair (see q3asr.h)."""
+        avg, nbytes, n = C.c_float(), C.c_double(), C.c_int32()
+        self._chk(self._lib.q3a_profile_weight_stream(self._h, reps, C.byref(avg), C.byref(nbytes), C.byref(n)))
+        return {"avg_us": float(avg.value), "bytes_per_launch": float(nbytes.value), "launches": int(n.value)}
+
     def debug_read(self, name: str) -> np.ndarray:
         n = C.c_uint64()
         self._chk(self._lib.q3a_debug_read(self._h, name.encode(), None, 0, C.byref(n)))

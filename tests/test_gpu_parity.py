@@ -194,6 +194,31 @@ def test_errors_are_reported(tiny_dir):
     eng.close()
 
 
+def test_parity_1p7b_dims_sharded_batch2():
+    """BASELINE configs[3] shape class: 1.7B dims (expected dims), sharded safetensors
+    (weights.rs:29-58), two ragged clips (the second one crosses the 8-chunk window boundary)."""
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b", "1.7b", seed=0, shards=2)
+    clips = [synthetic.synthetic_clip(0, 6.0), synthetic.synthetic_clip(1, 11.0)]
+    orc = O.AsrOracle(d)
+    refs = [orc.transcribe_ids(c, fixed_new_tokens=2, last_only=True, want_taps=True) for c in clips]
+    eng = HipEngine(d, 0, precise=True, max_new_tokens=8)
+    eng.mel(clips)
+    emb = eng.encode()
+    for b in range(2):
+        assert rel_l2(emb[b], refs[b].taps["audio_embeds"].numpy()) <= TOL[True]["rel"]
+    logits, nxt = eng.prefill([HipEngine.build_prompt(r.num_audio_tokens) for r in refs])
+    for b in range(2):
+        assert float(np.abs(logits[b] - refs[b].step_logits[0].numpy()).max()) <= TOL[True]["logit"]
+        assert int(nxt[b]) == refs[b].all_step_ids[0]
+    eng.set_next_tokens([r.all_step_ids[0] for r in refs])
+    lg, nx, _ = eng.decode_step()
+    for b in range(2):
+        assert float(np.abs(lg[b] - refs[b].step_logits[1].numpy()).max()) <= TOL[True]["logit"]
+        assert int(nx[b]) == refs[b].all_step_ids[1]
+    eng.close()
+    del orc, refs
+
+
 def test_parity_0p6b_dims_30s_clip():
     """BASELINE configs[1] shape: 0.6B dims (synthetic weights), one 30 s clip -> 4 attention windows
     (104,104,104,78), P=405.  Oracle uses last_only=True (same last-row logits, skips the all-position lm_head)."""
