@@ -20,7 +20,7 @@ OBJ_DIR = os.path.join(ROOT, "build", "q3asr")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libq3asr_hip.so")
 
-SOURCES = ["engine.cpp", "model.cpp", "k_gemm.hip", "k_mel.hip", "k_conv1.hip", "k_norm.hip", "k_attn.hip", "k_decode.hip", "k_gemv.hip", "k_dattn.hip", "k_fattn.hip"]
+SOURCES = ["engine.cpp", "model.cpp", "k_gemm.hip", "k_mel.hip", "k_conv1.hip", "k_norm.hip", "k_attn.hip", "k_decode.hip", "k_gemv.hip", "k_dattn.hip", "k_fattn.hip", "k_skinny.hip"]
 HEADERS = ["dev.h", "kernels.h", "model.h", "json.h", os.path.join("..", "..", "include", "q3asr.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]

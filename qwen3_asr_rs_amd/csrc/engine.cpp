@@ -470,8 +470,7 @@ struct q3a_engine {
       timed(Q3A_KC_GEMV_LM_HEAD, wbytes, [&] { KCHK(launch_gemv(g, S, stream)); });
     } else {
       timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(L.final_norm), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
-      GemmEpilogue ep; ep.out = logits.as<float>(); ep.ldo = V;
-      timed(Q3A_KC_GEMM, wbytes, [&] { KCHK(launch_gemm(s_ln.as<float>(), H, wh(L.lm_head), S, V, H, ep, false, precise(), stream)); });
+      timed(Q3A_KC_GEMM, wbytes, [&] { batched_proj(s_ln.as<float>(), H, wh(L.lm_head), V, H, nullptr, 0, logits.as<float>(), V, nullptr); });
       n_part = 128;
       timed(Q3A_KC_ARGMAX, 0, [&] { KCHK(launch_argmax_partials(logits.as<float>(), V, S, part_val.as<float>(), part_idx.as<int>(), part_stride, n_part, stream)); });
     }
@@ -538,6 +537,20 @@ struct q3a_engine {
 
   void scatter_audio_rows();
 
+  // decode-step projection for more than 4 sequences: skinny MFMA GEMM up to 32, generic tiles above
+  void batched_proj(const float* x, int ldx, const uint16_t* W, int N, int K, const float* bias, int mode, float* out,
+                    int ldo, const float* resid) {
+    const int S = B;
+    if (S <= 32) {
+      SkinnyArgs sk{};
+      sk.x = x; sk.ldx = ldx; sk.S = S; sk.W = W; sk.N = N; sk.K = K; sk.bias = bias; sk.mode = mode; sk.out = out; sk.ldo = ldo; sk.resid = resid;
+      KCHK(launch_skinny(sk, precise(), stream));
+    } else {
+      GemmEpilogue ep; ep.out = out; ep.ldo = ldo; ep.bias = bias; ep.resid = (mode == 1) ? resid : nullptr;
+      KCHK(launch_gemm(x, ldx, W, S, N, K, ep, mode == 2, precise(), stream));
+    }
+  }
+
   // one greedy-loop iteration for all sequences (inference.rs:160-200)
   void enqueue_decode_step() {
     const int S = B, H = d.hidden, I = d.inter, QD = d.q_dim(), QKV = d.qkv_dim();
@@ -557,8 +570,7 @@ struct q3a_engine {
         timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, stream)); });
       } else {
         timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(l.in_ln), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
-        GemmEpilogue ep; ep.out = s_qkv.as<float>(); ep.ldo = QKV; ep.bias = qkv_bias ? wf(l.qkv_b) : nullptr;
-        timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { KCHK(launch_gemm(s_ln.as<float>(), H, wh(l.qkv_w), S, QKV, H, ep, false, precise(), stream)); });
+        timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { batched_proj(s_ln.as<float>(), H, wh(l.qkv_w), QKV, H, qkv_bias ? wf(l.qkv_b) : nullptr, 0, s_qkv.as<float>(), QKV, nullptr); });
       }
       da.q_norm = wf(l.q_norm); da.k_norm = wf(l.k_norm); da.kcache = kc_layer(li); da.vcache = vc_layer(li);
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), stream)); });
@@ -583,21 +595,11 @@ struct q3a_engine {
         dn.mode = 1; dn.out = x_dec.as<float>(); dn.ldo = H; dn.resid = x_dec.as<float>();
         timed(Q3A_KC_GEMV_DOWN, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, stream)); });
       } else {
-        const bool sp = precise();
         timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream)); });
-        {
-          GemmEpilogue ep; ep.out = x_dec.as<float>(); ep.ldo = H; ep.resid = x_dec.as<float>(); ep.bias = o_bias ? wf(l.o_b) : nullptr;
-          timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { KCHK(launch_gemm(s_ctx.as<float>(), QD, wh(l.o_w), S, H, QD, ep, false, sp, stream)); });
-        }
+        timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { batched_proj(s_ctx.as<float>(), QD, wh(l.o_w), H, QD, o_bias ? wf(l.o_b) : nullptr, 1, x_dec.as<float>(), H, x_dec.as<float>()); });
         timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(l.post_ln), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
-        {
-          GemmEpilogue ep; ep.out = s_act.as<float>(); ep.ldo = I; ep.bias = mlp_bias ? wf(l.gu_b) : nullptr;
-          timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_gemm(s_ln.as<float>(), H, wh(l.gu_w), S, 2 * I, H, ep, true, sp, stream)); });
-        }
-        {
-          GemmEpilogue ep; ep.out = x_dec.as<float>(); ep.ldo = H; ep.resid = x_dec.as<float>(); ep.bias = mlp_bias ? wf(l.down_b) : nullptr;
-          timed(Q3A_KC_GEMM, 2.0 * H * I, [&] { KCHK(launch_gemm(s_act.as<float>(), I, wh(l.down_w), S, H, I, ep, false, sp, stream)); });
-        }
+        timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { batched_proj(s_ln.as<float>(), H, wh(l.gu_w), 2 * I, H, mlp_bias ? wf(l.gu_b) : nullptr, 2, s_act.as<float>(), I, nullptr); });
+        timed(Q3A_KC_GEMM, 2.0 * H * I, [&] { batched_proj(s_act.as<float>(), I, wh(l.down_w), H, I, mlp_bias ? wf(l.down_b) : nullptr, 1, x_dec.as<float>(), H, x_dec.as<float>()); });
       }
     }
     run_head(1);

@@ -117,6 +117,17 @@ constexpr int GEMV_ATTN_MAX_TABLE = 1024;  // min(NB,4) * heads * nsplit must fi
 int gemv_blocks(const GemvArgs& a);        // grid size launch_gemv uses (= number of argmax partials in mode 3)
 int gemv_rows_per_wave(const GemvArgs& a);
 
+// Skinny MFMA GEMM (k_skinny.hip): 4 < S <= 32 sequences, weights streamed once.
+struct SkinnyArgs {
+  const float* x; int ldx; int S;   // [S][K] fp32
+  const uint16_t* W; int N; int K;  // bf16 [N][K]
+  const float* bias;                // [N] or null
+  int mode;                         // 0: store, 1: out = resid + y, 2: GLU ([16 gate|16 up] row blocks, out has N/2 columns)
+  float* out; int ldo;
+  const float* resid;
+};
+const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s);
+
 struct DecodeAttnArgs {
   const float* qkv;            // [S][qkv_dim] fp32 (raw projections of the current token)
   const int* pos;              // [S] number of tokens already in the cache = position of the current token

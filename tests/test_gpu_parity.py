@@ -239,5 +239,9 @@ def test_parity_0p6b_dims_30s_clip():
             assert int(nxt[0]) == ref.all_step_ids[0]
             assert eng.transcribe_batch([clip], None, max_new=steps, fixed_new_tokens=steps)[0] == ref.all_step_ids[:steps]
         prof = eng.profile_decode_step()
-        assert prof["gemv"]["launches"] == 28 * 4 + 1 and abs(prof["gemv"]["weight_bytes"] - 1.192e9) < 2e6
+        gemv = [prof[k] for k in ("gemv_qkv_gateup", "gemv_o_proj", "gemv_down", "gemv_lm_head")]
+        assert [g["launches"] for g in gemv] == [56, 28, 28, 1]
+        assert abs(sum(g["weight_bytes"] for g in gemv) - 1.192e9) < 2e6   # 1.192 GB per token
+        ws = eng.profile_weight_stream(reps=1)
+        assert ws["launches"] == 56 and ws["bytes_per_launch"] == (4096 + 6144) * 1024 * 2 / 2 and ws["avg_us"] > 0
         eng.close()
