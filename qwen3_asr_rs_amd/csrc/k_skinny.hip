@@ -3,18 +3,24 @@
 // independent utterances; every weight byte is still streamed from HBM exactly once per step, now amortised
 // over up to 32 sequences.
 //
-// One workgroup = one tile of 32 weight rows; its 4 waves split K four ways.  Per 16-wide k-step a wave issues
-//   A = W fragment : lane (row l&31, k-chunk l>>5) loads its 16 B straight from the row-major bf16 matrix
-//   B = x fragment : lane (sequence l&31, same k-chunk) loads 8 fp32 activations (L2-resident) and rounds them
-//                    to bf16 (default) or splits them into bf16 hi + lo (precise mode: two MFMAs)
-//   v_mfma_f32_32x32x16_bf16 -> D[row][sequence]
-// then the four K-slices are summed through LDS and the epilogue (bias / residual / SiLU(gate)*up on the
-// [16 gate | 16 up] row blocks) is applied by all waves on a quarter of the tile each.
+// The step is latency-bound (a CU sustains only ~16 GB/s when it waits for one round trip per 8 KB), so the
+// kernel is shaped to put a workgroup's whole weight slab in flight at once: one workgroup = 16 weight rows
+// (32 in GLU mode: a 16-row gate tile + its 16-row up tile), 8 waves split K eight ways, and every wave issues
+// all loads of four 32-wide k-steps before its first MFMA.  Per k-step
+//   A = W fragment : lane (row l&15, k-chunk l>>4) loads its 16 B from the row-major bf16 matrix
+//                    (4 lanes cover 64 contiguous bytes of a row)
+//   B = x fragment : lane (sequence l&15 [+16], same k-chunk) loads 8 fp32 activations (L2-resident) and rounds
+//                    them to bf16 (default) or splits them into bf16 hi + lo (precise mode: two MFMAs)
+//   v_mfma_f32_16x16x32_bf16 -> D[row][sequence], sequences 0-15 and 16-31 share the A fragment.
+// The eight K-slices are summed through LDS in a fixed order (deterministic), then bias / residual /
+// SiLU(gate)*up are applied.
 #include "dev.h"
 #include "kernels.h"
 
 namespace q3a {
 namespace {
+
+constexpr int SK_WAVES = 8;
 
 __device__ __forceinline__ bf16x8_t pack8(const float4& a, const float4& b) {
   uint4 p;
@@ -30,64 +36,114 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, bf16x8_
   lo = *reinterpret_cast<const bf16x8_t*>(&l);
 }
 
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
-  __shared__ float part[4][32][33];  // [k-slice][row][sequence] (+1 pad)
+// TILES = 16-row weight tiles per workgroup (1, or 2 = gate + up); SH = 16-sequence halves (1: S <= 16, 2: S <= 32)
+template <bool SPLIT, int TILES, int SH>
+__global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
+  __shared__ float part[SK_WAVES][TILES][SH][16][17];  // [k-slice][tile][seq half][row][sequence] (+1 pad)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, half = lane >> 5;
-  const int n0 = blockIdx.x * 32;
+  const int l15 = lane & 15, kc = lane >> 4;  // row / sequence inside the fragment, k-chunk (8 elements)
+  const int n0 = blockIdx.x * 16 * TILES;
   const int K = a.K;
-  const int steps = K / 16, per = (steps + 3) / 4;
+  const int steps = K / 32, per = (steps + SK_WAVES - 1) / SK_WAVES;
   const int ks0 = wave * per, ks1 = min(steps, ks0 + per);
-  const int row = n0 + l31;
   // out-of-range rows / sequences are clamped to valid memory: their products are discarded by the epilogue
-  const uint16_t* wrow = a.W + (size_t)(row < a.N ? row : a.N - 1) * K + half * 8;
-  const float* xrow = a.x + (size_t)(l31 < a.S ? l31 : a.S - 1) * a.ldx + half * 8;
-
-  f32x16_t acc;
+  const uint16_t* wrow[TILES];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int ks = ks0; ks < ks1; ++ks) {
-    const uint4 wv = *reinterpret_cast<const uint4*>(wrow + ks * 16);
-    const float4 x0 = *reinterpret_cast<const float4*>(xrow + ks * 16);
-    const float4 x1 = *reinterpret_cast<const float4*>(xrow + ks * 16 + 4);
-    const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&wv);
-    if (SPLIT) {
-      bf16x8_t hi, lo;
-      split8(x0, x1, hi, lo);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, hi, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, lo, acc, 0, 0, 0);
-    } else {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, pack8(x0, x1), acc, 0, 0, 0);
-    }
+  for (int t = 0; t < TILES; ++t) {
+    const int row = n0 + t * 16 + l15;
+    wrow[t] = a.W + (size_t)(row < a.N ? row : a.N - 1) * K + kc * 8;
   }
-  // D[row i][sequence j]: j = lane&31, i = (r&3) + 8*(r>>2) + 4*half
+  const float* xrow[SH];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
+  for (int h = 0; h < SH; ++h) {
+    const int s = h * 16 + l15;
+    xrow[h] = a.x + (size_t)(s < a.S ? s : a.S - 1) * a.ldx + kc * 8;
+  }
+  f32x4_t acc[TILES][SH];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int h = 0; h < SH; ++h) acc[t][h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int UNR = 4;
+  for (int kb = ks0; kb < ks1; kb += UNR) {
+    uint4 wv[UNR][TILES];
+    float4 x0[UNR][SH], x1[UNR][SH];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const bool live = kb + u < ks1;
+      const int ks = live ? kb + u : ks1 - 1;  // clamp the address, zero the weight of the tail
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        wv[u][t] = *reinterpret_cast<const uint4*>(wrow[t] + ks * 32);
+        if (!live) wv[u][t] = make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int h = 0; h < SH; ++h) {
+        x0[u][h] = *reinterpret_cast<const float4*>(xrow[h] + ks * 32);
+        x1[u][h] = *reinterpret_cast<const float4*>(xrow[h] + ks * 32 + 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int h = 0; h < SH; ++h) {
+        bf16x8_t hi, lo;
+        if (SPLIT) split8(x0[u][h], x1[u][h], hi, lo);
+        else hi = pack8(x0[u][h], x1[u][h]);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+          const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&wv[u][t]);
+          acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hi, acc[t][h], 0, 0, 0);
+          if (SPLIT) acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, lo, acc[t][h], 0, 0, 0);
+        }
+      }
+  }
+  // D[row i][sequence j] of v_mfma_f32_16x16x32: j = lane&15, i = (lane>>4)*4 + r
+#pragma unroll
+  for (int t = 0; t < TILES; ++t)
+#pragma unroll
+    for (int h = 0; h < SH; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave][t][h][kc * 4 + r][l15] = acc[t][h][r];
   __syncthreads();
-  // ---- reduce the four K-slices; thread -> (sequence s = tid & 31, rows i0 .. i0+3) ----
-  const int s = tid & 31, i0 = (tid >> 5) * 4;
-  if (s >= a.S) return;
-  if (a.mode != 2) {
+  // ---- fixed-order reduction of the K-slices + epilogue: thread -> (row i, sequence s) ----
+  const int i = tid >> 5, s = tid & 31;  // 16 rows x 32 sequences = 512 threads
+  if (s >= a.S || (SH == 1 && s >= 16)) return;
+  const int sh = s >> 4, sj = s & 15;
+  float v[TILES];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = i0 + e, n = n0 + i;
-      if (n >= a.N) continue;
-      float v = part[0][i][s] + part[1][i][s] + part[2][i][s] + part[3][i][s];
-      if (a.bias) v += a.bias[n];
-      if (a.mode == 1) v += a.resid[(size_t)s * a.ldo + n];
-      a.out[(size_t)s * a.ldo + n] = v;
-    }
-  } else if (i0 < 16) {  // rows 0..15 = gate, 16..31 = up of logical rows (n0/2) .. (n0/2)+15
+  for (int t = 0; t < TILES; ++t) {
+    v[t] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = i0 + e;
-      if (n0 + 16 + i >= a.N) continue;
-      float g = part[0][i][s] + part[1][i][s] + part[2][i][s] + part[3][i][s];
-      float u = part[0][i + 16][s] + part[1][i + 16][s] + part[2][i + 16][s] + part[3][i + 16][s];
-      if (a.bias) { g += a.bias[n0 + i]; u += a.bias[n0 + 16 + i]; }
-      a.out[(size_t)s * a.ldo + (n0 >> 1) + i] = silu_f(g) * u;
-    }
+    for (int w = 0; w < SK_WAVES; ++w) v[t] += part[w][t][SH == 1 ? 0 : sh][i][sj];
+  }
+  if (TILES == 1) {
+    const int n = n0 + i;
+    if (n >= a.N) return;
+    float y = v[0];
+    if (a.bias) y += a.bias[n];
+    if (a.mode == 1) y += a.resid[(size_t)s * a.ldo + n];
+    a.out[(size_t)s * a.ldo + n] = y;
+  } else {  // rows n0..n0+15 = gate, n0+16..n0+31 = up of logical rows n0/2 .. n0/2+15
+    if (n0 + 16 + i >= a.N) return;
+    float g = v[0], u = v[TILES - 1];
+    if (a.bias) { g += a.bias[n0 + i]; u += a.bias[n0 + 16 + i]; }
+    a.out[(size_t)s * a.ldo + (n0 >> 1) + i] = silu_f(g) * u;
+  }
+}
+
+template <bool SPLIT>
+void launch_s(const SkinnyArgs& a, hipStream_t s) {
+  const dim3 block(SK_WAVES * 64);
+  if (a.mode == 2) {
+    const dim3 grid((a.N + 31) / 32);
+    if (a.S <= 16) hipLaunchKernelGGL((skinny_kernel<SPLIT, 2, 1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((skinny_kernel<SPLIT, 2, 2>), grid, block, 0, s, a);
+  } else {
+    const dim3 grid((a.N + 15) / 16);
+    if (a.S <= 16) hipLaunchKernelGGL((skinny_kernel<SPLIT, 1, 1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((skinny_kernel<SPLIT, 1, 2>), grid, block, 0, s, a);
   }
 }
 
@@ -96,11 +152,10 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
 const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s) {
   if (a.S <= 0) return nullptr;
   if (a.S > 32) return "skinny gemm: at most 32 sequences";
-  if (a.K % 16 != 0 || a.ldx % 4 != 0) return "skinny gemm: K must be a multiple of 16, ldx of 4";
+  if (a.K % 32 != 0 || a.ldx % 4 != 0) return "skinny gemm: K must be a multiple of 32, ldx of 4";
   if (a.mode == 2 && a.N % 32 != 0) return "skinny gemm: GLU needs N % 32 == 0";
-  const int blocks = (a.N + 31) / 32;
-  if (split) hipLaunchKernelGGL(skinny_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(skinny_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
+  if (split) launch_s<true>(a, s);
+  else launch_s<false>(a, s);
   return nullptr;
 }
 
