@@ -165,6 +165,31 @@ int32_t q3a_profile_weight_stream(q3a_engine* e, int32_t reps, float* avg_us, do
  * audio_embeds dec_embed dec_layer0 dec_last_hidden logits. */
 int32_t q3a_debug_read(q3a_engine* e, const char* name, void* dst, uint64_t bytes, uint64_t* actual);
 
+/* ---- pipeline shell: host-only helpers around the hot path -------------- */
+
+/* load_audio (src/audio.rs:7): RIFF/WAVE PCM s8/s16/s24/s32/f32 -> mono (channel mean, audio.rs:192-200) -> f32
+ * scaled by 1/2^(bits-1) (audio.rs:177) -> `target_sr` with this backend's deterministic windowed-sinc polyphase
+ * resampler (the reference's FFmpeg / rubato resamplers are not reproducible outside their code bases).
+ * *samples_out is malloc'ed; release it with q3a_free. */
+int32_t q3a_load_audio(const char* path, int32_t target_sr, float** samples_out, int64_t* n_out);
+int32_t q3a_resample(const float* in, int64_t n, int32_t sr_in, int32_t sr_out, float** samples_out, int64_t* n_out);
+void q3a_free(void* p);
+
+/* AsrTokenizer (src/tokenizer.rs:4-50) over HuggingFace's tokenizer.json (byte-level BPE). */
+typedef struct q3a_tokenizer q3a_tokenizer;
+int32_t q3a_tokenizer_create(const char* tokenizer_json_path, q3a_tokenizer** out);
+void q3a_tokenizer_destroy(q3a_tokenizer* t);
+/* decode(ids, skip_special_tokens) -> UTF-8 (tokenizer.rs:42-49). *len = bytes needed (excluding NUL). */
+int32_t q3a_tokenizer_decode(const q3a_tokenizer* t, const int32_t* ids, int32_t n, int32_t skip_special, char* out,
+                             int32_t cap, int32_t* len);
+/* encode(text, add_special_tokens = false) for ASCII prompts such as "language English" (tokenizer.rs:33-39). */
+int32_t q3a_tokenizer_encode(const q3a_tokenizer* t, const char* text, int32_t* ids, int32_t cap, int32_t* n);
+
+/* parse_asr_output (src/inference.rs:276-305); capitalize_first (inference.rs:307-313). */
+int32_t q3a_parse_asr_output(const char* raw, int32_t language_forced, char* language, int32_t language_cap, char* text,
+                             int32_t text_cap);
+int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
+
 /* Kernel self-tests against naive device references (no model needed): returns max abs error. */
 int32_t q3a_selftest_gemm(int32_t device, int32_t M, int32_t N, int32_t K, int32_t split, float* max_abs_err,
                           float* ref_abs_max);

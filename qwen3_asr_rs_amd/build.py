@@ -19,9 +19,12 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ_DIR = os.path.join(ROOT, "build", "q3asr")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libq3asr_hip.so")
+BIN_DIR = os.path.join(HERE, "bin")
+CLI_PATH = os.path.join(BIN_DIR, "asr")  # the reference's CLI (src/main.rs) on top of the C ABI
 
-SOURCES = ["engine.cpp", "model.cpp", "k_gemm.hip", "k_mel.hip", "k_conv1.hip", "k_norm.hip", "k_attn.hip", "k_decode.hip", "k_gemv.hip", "k_dattn.hip", "k_fattn.hip", "k_skinny.hip"]
-HEADERS = ["dev.h", "kernels.h", "model.h", "json.h", os.path.join("..", "..", "include", "q3asr.h")]
+SOURCES = ["engine.cpp", "model.cpp", "k_gemm.hip", "k_mel.hip", "k_conv1.hip", "k_norm.hip", "k_attn.hip", "k_decode.hip", "k_gemv.hip", "k_dattn.hip", "k_fattn.hip", "k_skinny.hip",
+           "host_audio.cpp", "host_text.cpp", "host_abi.cpp"]
+HEADERS = ["dev.h", "kernels.h", "model.h", "json.h", "host.h", os.path.join("..", "..", "include", "q3asr.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
@@ -72,6 +75,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(f"[q3asr build] linked {LIB_PATH}")
     elif verbose:
         print(f"[q3asr build] up to date: {LIB_PATH}")
+    # CLI binary: plain C++ over the C ABI, finds the library through $ORIGIN/../lib
+    os.makedirs(BIN_DIR, exist_ok=True)
+    cli_src = os.path.join(CSRC, "asr_main.cpp")
+    cli_stamp = CLI_PATH + ".stamp"
+    cli_want = _hash([cli_src, os.path.join(ROOT, "include", "q3asr.h")]) + want
+    if force or not os.path.exists(CLI_PATH) or not os.path.exists(cli_stamp) or open(cli_stamp).read() != cli_want:
+        cmd = ["g++", "-O2", "-std=c++17", "-o", CLI_PATH, cli_src, "-L" + LIB_DIR, "-lq3asr_hip", "-Wl,-rpath,$ORIGIN/../lib",
+               "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"CLI link failed:\n{r.stdout}\n{r.stderr}")
+        with open(cli_stamp, "w") as f:
+            f.write(cli_want)
+        if verbose:
+            print(f"[q3asr build] linked {CLI_PATH}")
     return LIB_PATH
 
 

@@ -81,6 +81,10 @@ struct ProfEvent {
 
 }  // namespace
 
+namespace q3a {
+void set_thread_error(const std::string& msg) { g_last_error = msg; }  // used by host_abi.cpp
+}  // namespace q3a
+
 struct q3a_engine {
   Dims d;
   ArenaLayout L;

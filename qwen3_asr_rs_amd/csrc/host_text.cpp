@@ -1,0 +1,271 @@
+// Byte-level BPE tokenizer over HuggingFace's tokenizer.json and the output parsing of the pipeline shell.
+// Replaces src/tokenizer.rs (which wraps the `tokenizers` crate, a dependency outside the reference tree) for
+// the two uses the path has: decode(generated ids, skip_special_tokens = true) (tokenizer.rs:42-49,
+// inference.rs:204) and encode("language {Lang}") for a forced language (tokenizer.rs:33-39,
+// inference.rs:249-250); and src/inference.rs:276-313 (parse_asr_output, capitalize_first).
+#include <algorithm>
+#include <climits>
+#include <fstream>
+#include <sstream>
+
+#include "host.h"
+#include "json.h"
+#include "model.h"
+
+namespace q3a {
+
+namespace {
+
+std::string utf8_of(uint32_t cp) {
+  std::string s;
+  if (cp < 0x80) s += (char)cp;
+  else if (cp < 0x800) { s += (char)(0xC0 | (cp >> 6)); s += (char)(0x80 | (cp & 0x3F)); }
+  else if (cp < 0x10000) { s += (char)(0xE0 | (cp >> 12)); s += (char)(0x80 | ((cp >> 6) & 0x3F)); s += (char)(0x80 | (cp & 0x3F)); }
+  else { s += (char)(0xF0 | (cp >> 18)); s += (char)(0x80 | ((cp >> 12) & 0x3F)); s += (char)(0x80 | ((cp >> 6) & 0x3F)); s += (char)(0x80 | (cp & 0x3F)); }
+  return s;
+}
+// decode one UTF-8 code point starting at s[i]; advances i (invalid bytes come back as themselves)
+uint32_t next_cp(const std::string& s, size_t& i) {
+  unsigned char c = (unsigned char)s[i];
+  int n = c < 0x80 ? 0 : (c >> 5) == 6 ? 1 : (c >> 4) == 14 ? 2 : (c >> 3) == 30 ? 3 : -1;
+  if (n <= 0 || i + (size_t)n >= s.size()) { ++i; return c; }  // ASCII, bad lead byte or truncated sequence
+  uint32_t cp = c & (0xFF >> (n + 2));
+  for (int k = 1; k <= n; ++k) cp = (cp << 6) | ((unsigned char)s[i + k] & 0x3F);
+  i += (size_t)n + 1;
+  return cp;
+}
+
+std::string read_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) fail("Failed to load tokenizer: cannot open " + path);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+
+bool is_letter(unsigned char c) { return (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'); }
+bool is_digit(unsigned char c) { return c >= '0' && c <= '9'; }
+bool is_space(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+// Qwen2 pre-tokenisation pattern restricted to ASCII:
+// (?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+
+size_t match_piece(const std::string& t, size_t i) {
+  const size_t n = t.size();
+  auto lower = [&](size_t k) { return (char)tolower((unsigned char)t[k]); };
+  if (t[i] == '\'' && i + 1 < n) {
+    char a = lower(i + 1);
+    if (a == 's' || a == 't' || a == 'm' || a == 'd') return i + 2;
+    if (i + 2 < n) {
+      char b = lower(i + 2);
+      if ((a == 'r' && b == 'e') || (a == 'v' && b == 'e') || (a == 'l' && b == 'l')) return i + 3;
+    }
+  }
+  {  // [^\r\n L N]? L+
+    size_t j = i;
+    unsigned char c = (unsigned char)t[j];
+    if (!(c == '\r' || c == '\n' || is_letter(c) || is_digit(c)) && j + 1 < n && is_letter((unsigned char)t[j + 1])) ++j;
+    if (is_letter((unsigned char)t[j])) {
+      while (j < n && is_letter((unsigned char)t[j])) ++j;
+      return j;
+    }
+  }
+  if (is_digit((unsigned char)t[i])) return i + 1;
+  {  // " ?[^\s L N]+[\r\n]*"
+    size_t j = i;
+    if (t[j] == ' ' && j + 1 < n) ++j;
+    auto other = [&](size_t k) { unsigned char c = (unsigned char)t[k]; return !is_space(c) && !is_letter(c) && !is_digit(c); };
+    if (j < n && other(j)) {
+      while (j < n && other(j)) ++j;
+      while (j < n && (t[j] == '\r' || t[j] == '\n')) ++j;
+      return j;
+    }
+  }
+  if (is_space((unsigned char)t[i])) {
+    size_t j = i;
+    while (j < n && is_space((unsigned char)t[j])) ++j;  // maximal whitespace run [i, j)
+    size_t last_nl = std::string::npos;
+    for (size_t k = i; k < j; ++k)
+      if (t[k] == '\r' || t[k] == '\n') last_nl = k;
+    if (last_nl != std::string::npos) return last_nl + 1;      // \s*[\r\n]+
+    if (j == n) return j;                                       // \s+(?!\S) at end of text
+    if (j - i > 1) return j - 1;                                // \s+(?!\S): leave one space for the next piece
+    return j;                                                   // \s+
+  }
+  return i + 1;
+}
+
+}  // namespace
+
+BpeTokenizer::BpeTokenizer(const std::string& path) {
+  Json root = parse_json(read_file(path));
+  const Json& model = root.at("model");
+  const Json& vocab = model.at("vocab");
+  if (vocab.kind != Json::Obj) fail("tokenizer.json: model.vocab missing");
+  size_t max_id = 0;
+  for (auto& kv : vocab.obj) max_id = std::max(max_id, (size_t)kv.second.num);
+  if (const Json* added = root.find("added_tokens"))
+    for (auto& t : added->arr) max_id = std::max(max_id, (size_t)t.at("id").num);
+  id_to_token_.assign(max_id + 1, std::string());
+  is_special_.assign(max_id + 1, false);
+  is_added_.assign(max_id + 1, false);
+  for (auto& kv : vocab.obj) {
+    id_to_token_[(size_t)kv.second.num] = kv.first;
+    token_to_id_[kv.first] = (int64_t)kv.second.num;
+  }
+  if (const Json* added = root.find("added_tokens"))
+    for (auto& t : added->arr) {
+      size_t id = (size_t)t.at("id").num;
+      id_to_token_[id] = t.at("content").str;
+      token_to_id_[t.at("content").str] = (int64_t)id;
+      is_added_[id] = true;
+      is_special_[id] = t.bool_or("special", false);
+    }
+  if (const Json* merges = model.find("merges")) {
+    int rank = 0;
+    for (auto& m : merges->arr) {
+      if (m.kind == Json::Str) merge_rank_[m.str] = rank++;                                   // "left right"
+      else if (m.kind == Json::Arr && m.arr.size() == 2) merge_rank_[m.arr[0].str + " " + m.arr[1].str] = rank++;
+    }
+  }
+  // GPT-2 byte <-> unicode table: printable bytes map to themselves, the rest to U+0100 + n
+  byte_of_cp_.assign(512, -1);
+  cp_of_byte_.resize(256);
+  int extra = 0;
+  for (int b = 0; b < 256; ++b) {
+    bool keep = (b >= 33 && b <= 126) || (b >= 161 && b <= 172) || (b >= 174 && b <= 255);
+    uint32_t cp = keep ? (uint32_t)b : (uint32_t)(256 + extra++);
+    byte_of_cp_[cp] = b;
+    cp_of_byte_[b] = utf8_of(cp);
+  }
+}
+
+std::string BpeTokenizer::decode(const std::vector<int64_t>& ids, bool skip_special) const {
+  std::string bytes;
+  for (int64_t id : ids) {
+    if (id < 0 || (size_t)id >= id_to_token_.size()) continue;
+    if (skip_special && is_special_[(size_t)id]) continue;
+    const std::string& tok = id_to_token_[(size_t)id];
+    // ByteLevel decoder: every char -> byte; a token containing an unmapped char is passed through as UTF-8
+    std::string conv;
+    bool ok = true;
+    for (size_t i = 0; i < tok.size();) {
+      uint32_t cp = next_cp(tok, i);
+      if (cp < byte_of_cp_.size() && byte_of_cp_[cp] >= 0) conv += (char)byte_of_cp_[cp];
+      else { ok = false; break; }
+    }
+    bytes += ok ? conv : tok;
+  }
+  // String::from_utf8_lossy: replace malformed sequences by U+FFFD
+  std::string out;
+  for (size_t i = 0; i < bytes.size();) {
+    unsigned char c = (unsigned char)bytes[i];
+    int n = c < 0x80 ? 0 : (c >= 0xC2 && c <= 0xDF) ? 1 : (c >= 0xE0 && c <= 0xEF) ? 2 : (c >= 0xF0 && c <= 0xF4) ? 3 : -1;
+    bool good = n >= 0 && i + (size_t)n < bytes.size();
+    if (good)
+      for (int k = 1; k <= n; ++k)
+        if (((unsigned char)bytes[i + k] & 0xC0) != 0x80) { good = false; break; }
+    if (good) { out.append(bytes, i, (size_t)n + 1); i += (size_t)n + 1; }
+    else { out += "\xEF\xBF\xBD"; ++i; }
+  }
+  return out;
+}
+
+std::vector<int64_t> BpeTokenizer::encode(const std::string& text) const {
+  for (unsigned char c : text)
+    if (c >= 0x80) fail("Tokenization failed: this encoder handles ASCII prompts only (got a non-ASCII byte)");
+  std::vector<int64_t> ids;
+  for (size_t i = 0; i < text.size();) {
+    size_t j = match_piece(text, i);
+    std::vector<std::string> sym;
+    for (size_t k = i; k < j; ++k) sym.push_back(cp_of_byte_[(unsigned char)text[k]]);
+    while (sym.size() > 1) {  // merge the lowest-ranked adjacent pair until none is left
+      int best = INT_MAX;
+      size_t at = 0;
+      for (size_t k = 0; k + 1 < sym.size(); ++k) {
+        auto it = merge_rank_.find(sym[k] + " " + sym[k + 1]);
+        if (it != merge_rank_.end() && it->second < best) { best = it->second; at = k; }
+      }
+      if (best == INT_MAX) break;
+      sym[at] += sym[at + 1];
+      sym.erase(sym.begin() + (long)at + 1);
+    }
+    for (auto& s : sym) {
+      auto it = token_to_id_.find(s);
+      if (it == token_to_id_.end()) fail("Tokenization failed: symbol not in vocabulary");
+      ids.push_back(it->second);
+    }
+    i = j;
+  }
+  return ids;
+}
+
+// ---------------------------------------------------------------------------------------------------
+namespace {
+bool cp_is_space(uint32_t cp) {
+  return cp == ' ' || (cp >= 9 && cp <= 13) || cp == 0x85 || cp == 0xA0 || cp == 0x1680 || (cp >= 0x2000 && cp <= 0x200A) ||
+         cp == 0x2028 || cp == 0x2029 || cp == 0x202F || cp == 0x205F || cp == 0x3000;
+}
+// char::is_alphabetic approximation: ASCII letters; outside ASCII everything except whitespace, general/CJK
+// punctuation and symbol blocks (exact Unicode tables are not needed for "language <Name> text" outputs)
+bool cp_is_alpha(uint32_t cp) {
+  if (cp < 0x80) return (cp >= 'A' && cp <= 'Z') || (cp >= 'a' && cp <= 'z');
+  if (cp_is_space(cp)) return false;
+  if ((cp >= 0xA1 && cp <= 0xBF && cp != 0xAA && cp != 0xB5 && cp != 0xBA) || cp == 0xD7 || cp == 0xF7) return false;
+  if ((cp >= 0x2000 && cp <= 0x2BFF) || (cp >= 0x3000 && cp <= 0x303F) || (cp >= 0xFF00 && cp <= 0xFF20) ||
+      (cp >= 0xFF3B && cp <= 0xFF40) || (cp >= 0xFF5B && cp <= 0xFF65) || (cp >= 0xFE30 && cp <= 0xFE6F))
+    return false;
+  return true;
+}
+std::string trim(const std::string& s) {  // str::trim (Unicode white space)
+  size_t b = 0, e = s.size();
+  while (b < e) { size_t i = b; uint32_t cp = next_cp(s, i); if (!cp_is_space(cp)) break; b = i; }
+  while (e > b) {
+    size_t k = e - 1;
+    while (k > b && ((unsigned char)s[k] & 0xC0) == 0x80) --k;
+    size_t i = k;
+    uint32_t cp = next_cp(s, i);
+    if (!cp_is_space(cp)) break;
+    e = k;
+  }
+  return s.substr(b, e - b);
+}
+}  // namespace
+
+void parse_asr_output(const std::string& raw_in, bool language_forced, std::string& language, std::string& text) {
+  if (language_forced) { language = "forced"; text = trim(raw_in); return; }  // inference.rs:277-279
+  const std::string raw = trim(raw_in);
+  const std::string pre = "language ";
+  if (raw.compare(0, pre.size(), pre) == 0) {
+    const std::string rest = raw.substr(pre.size());
+    const std::string tag = "<asr_text>";
+    size_t p = rest.find(tag);
+    if (p != std::string::npos) {  // inference.rs:284-288
+      language = trim(rest.substr(0, p));
+      text = trim(rest.substr(p + tag.size()));
+      return;
+    }
+    size_t lang_end = 0;  // inference.rs:289-301
+    for (size_t i = 0; i < rest.size();) {
+      size_t start = i;
+      uint32_t cp = next_cp(rest, i);
+      if (cp_is_space(cp) || !cp_is_alpha(cp)) { lang_end = start; break; }
+      lang_end = i;
+    }
+    if (lang_end > 0) {
+      language = rest.substr(0, lang_end);
+      text = trim(rest.substr(lang_end));
+      return;
+    }
+  }
+  language = "unknown";
+  text = raw;
+}
+
+std::string capitalize_first(const std::string& s) {  // inference.rs:307-313 (ASCII upper-casing of the first char)
+  if (s.empty()) return s;
+  std::string r = s;
+  if ((unsigned char)r[0] < 0x80) r[0] = (char)toupper((unsigned char)r[0]);
+  return r;
+}
+
+}  // namespace q3a

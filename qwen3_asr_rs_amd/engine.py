@@ -216,30 +216,7 @@ def selftest_gemm(M: int, N: int, K: int, split: bool = False, device: int = 0) 
 # ------------------------------------------------------------------------------------------------------
 # Reference-shaped front door
 # ------------------------------------------------------------------------------------------------------
-def capitalize_first(s: str) -> str:
-    """src/inference.rs:307-313"""
-    return s[:1].upper() + s[1:] if s else s
-
-
-def parse_asr_output(raw: str, language_forced: bool) -> Tuple[str, str]:
-    """src/inference.rs:276-305"""
-    if language_forced:
-        return "forced", raw.strip()
-    raw = raw.strip()
-    if raw.startswith("language "):
-        rest = raw[len("language "):]
-        p = rest.find("<asr_text>")
-        if p >= 0:
-            return rest[:p].strip(), rest[p + len("<asr_text>"):].strip()
-        lang_end = 0
-        for i, c in enumerate(rest):
-            if c.isspace() or not c.isalpha():
-                lang_end = i
-                break
-            lang_end = i + 1
-        if lang_end > 0:
-            return rest[:lang_end], rest[lang_end:].strip()
-    return "unknown", raw
+from .audio import AsrTokenizer, capitalize_first, load_audio, parse_asr_output  # noqa: E402  (C++ host code behind the C ABI)
 
 
 @dataclass
@@ -266,14 +243,12 @@ class AsrInference:
         tok = None
         tj = os.path.join(model_dir, "tokenizer.json")
         if os.path.exists(tj):
-            import tokenizers  # host-side string glue only
-            tok = tokenizers.Tokenizer.from_file(tj)
+            tok = AsrTokenizer(tj)
         return cls(eng, tok)
 
     def transcribe(self, audio, language: Optional[str] = None, max_new_tokens: int = 4096) -> TranscribeResult:
         """src/inference.rs:89-213.  `audio`: path to a WAV file or a 16 kHz float32 array."""
         if isinstance(audio, (str, os.PathLike)):
-            from .audio import load_audio
             samples = load_audio(os.fspath(audio), 16000)
         else:
             samples = np.asarray(audio, dtype=np.float32)
@@ -281,8 +256,8 @@ class AsrInference:
         if language is not None:
             if self.tokenizer is None:
                 raise Q3aError("forcing a language needs tokenizer.json (src/inference.rs:246-251)")
-            prefix = self.tokenizer.encode("language " + capitalize_first(language), add_special_tokens=False).ids
+            prefix = self.tokenizer.encode("language " + capitalize_first(language))
         ids = self.engine.transcribe_batch([samples], prefix, max_new_tokens)[0]
-        raw = self.tokenizer.decode(ids, skip_special_tokens=True) if self.tokenizer is not None else ""
+        raw = self.tokenizer.decode(ids, True) if self.tokenizer is not None else ""
         lang, text = parse_asr_output(raw, language is not None)
         return TranscribeResult(text, lang, raw, ids)

@@ -245,3 +245,38 @@ def test_parity_0p6b_dims_30s_clip():
         ws = eng.profile_weight_stream(reps=1)
         assert ws["launches"] == 56 and ws["bytes_per_launch"] == (4096 + 6144) * 1024 * 2 / 2 and ws["avg_us"] > 0
         eng.close()
+
+
+def test_cli_end_to_end(tiny_dir, tmp_path):
+    """`asr <model_dir> <wav> [language]` (src/main.rs:7-81): stdout contract and agreement with the library path.
+    The model directory gets a synthetic tokenizer.json (id i <-> token "t{i}", two special ids)."""
+    import json
+    import shutil
+    import subprocess
+    import wave
+    from qwen3_asr_rs_amd.build import CLI_PATH
+    from qwen3_asr_rs_amd.engine import AsrInference
+    mdir = tmp_path / "model"
+    mdir.mkdir()
+    for f in os.listdir(tiny_dir):
+        if f.endswith((".json", ".safetensors")):
+            os.symlink(os.path.join(tiny_dir, f), mdir / f)
+    vocab = {f"t{i}": i for i in range(151936) if i not in (151643, 151645)}
+    tok = {"version": "1.0", "added_tokens": [{"id": 151643, "content": "<|endoftext|>", "special": True},
+                                              {"id": 151645, "content": "<|im_end|>", "special": True}],
+           "model": {"type": "BPE", "vocab": vocab, "merges": []}}
+    (mdir / "tokenizer.json").write_text(json.dumps(tok))
+    clip = synthetic.synthetic_clip(11, 2.0)
+    wav = tmp_path / "clip.wav"
+    with wave.open(str(wav), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(24000)
+        x24 = np.interp(np.arange(int(len(clip) * 1.5)) / 1.5, np.arange(len(clip)), clip)
+        w.writeframes((np.clip(x24, -1, 1) * 32767).astype("<i2").tobytes())
+    r = subprocess.run([CLI_PATH, str(mdir), str(wav)], capture_output=True, text=True, timeout=300, env=dict(os.environ, RUST_LOG="warn"))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert len(lines) == 2 and lines[0].startswith("Language: ") and lines[1].startswith("Text: ")
+    res = AsrInference.load(str(mdir), 0).transcribe(str(wav))
+    assert len(res.ids) == 4096                              # random weights never emit EOS: the reference's cap (inference.rs:153)
+    assert lines[0] == f"Language: {res.language}" and lines[1] == f"Text: {res.text}"
+    assert res.raw_output.startswith(f"t{res.ids[0]}t{res.ids[1]}")

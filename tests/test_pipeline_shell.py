@@ -1,0 +1,154 @@
+"""CPU tests of the pipeline-shell rows: WAV ingest + resampler, byte-level BPE
+tokenizer, output parsing and the `asr` CLI's argv contract -- all C++ behind the C ABI, checked against
+independent Python implementations (wave/numpy/scipy, HuggingFace `tokenizers`, the oracle's parser)."""
+import os
+import struct
+import subprocess
+import wave
+
+import numpy as np
+import pytest
+
+from oracle import q3asr_oracle as O
+from qwen3_asr_rs_amd import audio
+from qwen3_asr_rs_amd.build import CLI_PATH
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _write_wav(path, data, sr, nch, sampwidth=2, fmt=1):
+    """Tiny RIFF writer (s16/s24/s32/f32, interleaved)."""
+    data = np.asarray(data)
+    if fmt == 3:
+        raw = data.astype("<f4").tobytes()
+        bits = 32
+    elif sampwidth == 3:
+        v = data.astype(np.int32)
+        raw = b"".join(struct.pack("<i", int(x))[:3] for x in v.ravel())
+        bits = 24
+    else:
+        raw = data.astype({1: np.uint8, 2: "<i2", 4: "<i4"}[sampwidth]).tobytes()
+        bits = 8 * sampwidth
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, fmt, nch, sr, sr * nch * bits // 8, nch * bits // 8, bits)
+    open(path, "wb").write(hdr + b"data" + struct.pack("<I", len(raw)) + raw)
+
+
+def test_wav_reader_matches_python_wave(lib):
+    """The reference's three clips (24 kHz mono s16): same samples as Python's wave module, scale 1/32768."""
+    for i in (1, 2, 3):
+        p = os.path.join(GOLDEN, "test_audio", f"sample{i}.wav")
+        with wave.open(p) as w:
+            sr, n = w.getframerate(), w.getnframes()
+            ref = np.frombuffer(w.readframes(n), dtype="<i2").astype(np.float32) / 32768.0
+        got = audio.load_audio(p, sr)  # same rate -> no resampling
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+        assert len(audio.load_audio(p, 16000)) == (n * 2 + 2) // 3   # ceil(n * 2/3): 128000 / 66560 / 89600
+
+
+def test_wav_formats_and_downmix(lib, tmp_path):
+    rng = np.random.default_rng(0)
+    x = rng.integers(-20000, 20000, size=(500, 2))
+    _write_wav(tmp_path / "s16.wav", x, 16000, 2, 2)
+    np.testing.assert_allclose(audio.load_audio(str(tmp_path / "s16.wav"), 16000), (x / 32768.0).mean(1), atol=1e-7)  # audio.rs:192-200
+    x24 = rng.integers(-(1 << 22), 1 << 22, size=(300, 1))
+    _write_wav(tmp_path / "s24.wav", x24, 16000, 1, 3)
+    np.testing.assert_allclose(audio.load_audio(str(tmp_path / "s24.wav"), 16000), x24[:, 0] / float(1 << 23), atol=1e-7)
+    xf = rng.standard_normal((200, 1)).astype(np.float32) * 0.1
+    _write_wav(tmp_path / "f32.wav", xf, 16000, 1, 4, fmt=3)
+    assert np.array_equal(audio.load_audio(str(tmp_path / "f32.wav"), 16000), xf[:, 0])
+    with pytest.raises(RuntimeError, match="not a RIFF"):
+        (tmp_path / "bad.wav").write_bytes(b"hello world, not audio")
+        audio.load_audio(str(tmp_path / "bad.wav"), 16000)
+    with pytest.raises(RuntimeError, match="not found"):
+        audio.load_audio(str(tmp_path / "missing.wav"), 16000)
+
+
+def test_resampler_properties(lib):
+    from scipy.signal import resample_poly
+    sr_in, sr_out = 24000, 16000
+    t = np.arange(sr_in) / sr_in
+    # in-band sines keep frequency, phase and amplitude; the 10 kHz tone (above the 8 kHz output Nyquist) is removed
+    x = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.25 * np.sin(2 * np.pi * 3000 * t + 0.3)).astype(np.float32)
+    y = audio.resample(x, sr_in, sr_out)
+    assert len(y) == 16000
+    to = np.arange(len(y)) / sr_out
+    ref = 0.5 * np.sin(2 * np.pi * 440 * to) + 0.25 * np.sin(2 * np.pi * 3000 * to + 0.3)
+    assert np.abs(y[200:-200] - ref[200:-200]).max() < 2e-3
+    alias = audio.resample(np.sin(2 * np.pi * 10000 * t).astype(np.float32), sr_in, sr_out)
+    assert np.abs(alias[200:-200]).max() < 2e-3
+    # agrees with scipy's polyphase resampler on band-limited noise (different filters, same pass band)
+    rng = np.random.default_rng(1)
+    n = rng.standard_normal(sr_in)
+    n = np.convolve(n, np.hanning(31) / np.hanning(31).sum(), mode="same").astype(np.float32)
+    a, b = audio.resample(n, sr_in, sr_out), resample_poly(n.astype(np.float64), 2, 3)
+    assert np.abs(a[300:-300] - b[300:-300]).max() < 0.02 * np.abs(b).max()
+    assert np.array_equal(audio.resample(x, 16000, 16000), x)                      # identity
+    assert np.array_equal(audio.resample(x, sr_in, sr_out), y)                      # deterministic
+    assert len(audio.resample(x[:1001], 44100, 16000)) == (1001 * 160 + 440) // 441
+
+
+@pytest.fixture(scope="module")
+def bpe_json(tmp_path_factory):
+    """A small byte-level BPE tokenizer.json with Qwen2's pre-tokeniser pattern and Qwen-style added tokens,
+    trained with HuggingFace `tokenizers` (no real Qwen tokenizer exists offline)."""
+    tokenizers = pytest.importorskip("tokenizers")
+    from tokenizers import Regex, Tokenizer, decoders, models, pre_tokenizers, trainers
+    tok = Tokenizer(models.BPE())
+    pat = r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"
+    tok.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split(Regex(pat), behavior="isolated"),
+                                                 pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)])
+    tok.decoder = decoders.ByteLevel()
+    corpus = ["language English the quick brown fox jumps over the lazy dog " * 3, "language Chinese 你好，这是语音识别测试。",
+              "Thank you for your contribution, it's 2024! We'll see.\n\nNew line here.", "language Japanese こんにちは 12345 ...  spaces   "]
+    tok.train_from_iterator(corpus * 4, trainers.BpeTrainer(vocab_size=600, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(), show_progress=False))
+    tok.add_special_tokens(["<|endoftext|>", "<|im_start|>", "<|im_end|>"])
+    tok.add_tokens(["<asr_text>"])
+    d = tmp_path_factory.mktemp("tok")
+    path = str(d / "tokenizer.json")
+    tok.save(path)
+    return path, tok
+
+
+def test_tokenizer_decode_matches_hf(lib, bpe_json):
+    path, hf = bpe_json
+    mine = audio.AsrTokenizer(path)
+    texts = ["language English<asr_text>Thank you for your contribution, it's 2024!", "language Chinese<asr_text>你好，这是语音识别测试。",
+             "  spaces   and\n\nnewlines ", "こんにちは 12345"]
+    sp = hf.token_to_id("<|im_end|>")
+    for t in texts:
+        ids = hf.encode(t, add_special_tokens=False).ids + [sp]
+        assert mine.decode(ids, True) == hf.decode(ids, skip_special_tokens=True)
+        assert mine.decode(ids, False) == hf.decode(ids, skip_special_tokens=False)
+    # a multi-byte character split across two tokens decodes lossily exactly like String::from_utf8_lossy
+    ids = hf.encode("你", add_special_tokens=False).ids
+    if len(ids) > 1:
+        assert mine.decode(ids[:1]) == hf.decode(ids[:1])
+
+
+def test_tokenizer_encode_ascii_matches_hf(lib, bpe_json):
+    path, hf = bpe_json
+    mine = audio.AsrTokenizer(path)
+    for t in ["language English", "language Chinese", "language Japanese", "it's we'll  two  spaces 42 !? end ", "a\n\nb \n c", "x,y.z"]:
+        assert mine.encode(t) == hf.encode(t, add_special_tokens=False).ids, t
+    with pytest.raises(RuntimeError, match="ASCII"):
+        mine.encode("语言")
+
+
+def test_parse_and_capitalize_match_oracle(lib):
+    cases = [("language English<asr_text>Hello there.", False), ("  language Chinese 你好", False), ("no prefix", False),
+             (" raw text ", True), ("language  <asr_text> x ", False), ("language", False), ("language English", False),
+             ("language Deutsch-Text hier", False), ("", False)]
+    for raw, forced in cases:
+        assert audio.parse_asr_output(raw, forced) == O.parse_asr_output(raw, forced), raw
+    for s in ["english", "", "Chinese", "x"]:
+        assert audio.capitalize_first(s) == O.capitalize_first(s)
+
+
+def test_cli_argv_contract(lib, tmp_path):
+    """src/main.rs:16-48: usage + exit 1 with fewer than 2 arguments; missing paths are errors."""
+    r = subprocess.run([CLI_PATH], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage: asr <model_path> <audio_file> [language]" in r.stderr and r.stdout == ""
+    r = subprocess.run([CLI_PATH, str(tmp_path / "nope"), "x.wav"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Model directory not found" in r.stderr
+    r = subprocess.run([CLI_PATH, str(tmp_path), str(tmp_path / "x.wav")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Audio file not found" in r.stderr
