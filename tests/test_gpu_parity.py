@@ -182,6 +182,38 @@ def test_forced_language_prefix(tiny_dir):
     eng.close()
 
 
+def test_replica_from_broadcast_arena(tiny_dir):
+    """The multi-GPU start-up path on one GPU: pack the arena on the host, move the bytes into a torch device tensor
+    (what dist.broadcast delivers on every rank) and create the engine from that pointer."""
+    from qwen3_asr_rs_amd.distributed import pack_arena_host
+    clip = synthetic.synthetic_clip(12, 2.5)
+    ref_eng = HipEngine(tiny_dir, 0, max_new_tokens=8)
+    ref = ref_eng.transcribe_batch([clip], None, max_new=6, fixed_new_tokens=6)[0]
+    ref_eng.close()
+    arena = pack_arena_host(tiny_dir).to("cuda:0")
+    torch.cuda.synchronize()
+    eng = HipEngine(tiny_dir, 0, max_new_tokens=8, device_arena=(arena.data_ptr(), arena.numel()))
+    assert eng.transcribe_batch([clip], None, max_new=6, fixed_new_tokens=6)[0] == ref
+    eng.close()
+    from qwen3_asr_rs_amd.engine import Q3aError
+    with pytest.raises(Q3aError, match="arena"):
+        HipEngine(tiny_dir, 0, device_arena=(arena.data_ptr(), arena.numel() - 256))
+
+
+def test_long_audio_many_windows_and_long_context(tiny_dir):
+    """61.3 s clip: 62 chunks -> 8 attention windows in the encoder, prompt of ~800 tokens -> the decode step
+    runs over 7+ key splits (flash-decoding merge in the o_proj GEMV); plus an exact multiple of the chunk size."""
+    clips = [synthetic.synthetic_clip(20, 61.3)]
+    _stage_check(tiny_dir, clips, True, steps=3)
+    _stage_check(tiny_dir, [synthetic.synthetic_clip(21, 8.0)], False, steps=2)   # 800 frames = 8 full chunks: no window mask in the reference
+
+
+def test_minimum_length_audio(tiny_dir):
+    """161 samples is the shortest input reflection padding accepts (mel.rs:63-65): two frames, one chunk, one token."""
+    clip = synthetic.synthetic_clip(22, 1.0)[:161]
+    _stage_check(tiny_dir, [clip], True, steps=2)
+
+
 def test_errors_are_reported(tiny_dir):
     from qwen3_asr_rs_amd.engine import Q3aError
     eng = HipEngine(tiny_dir, 0)
