@@ -193,6 +193,10 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
 /* Kernel self-tests against naive device references (no model needed): returns max abs error. */
 int32_t q3a_selftest_gemm(int32_t device, int32_t M, int32_t N, int32_t K, int32_t split, float* max_abs_err,
                           float* ref_abs_max);
+/* Same for the bf16-activation GEMM (global_load_lds path); with reps > 0 also the average launch time of it and
+ * of the fp32-activation kernel on the same shape (HIP events around `reps` back-to-back launches). */
+int32_t q3a_selftest_gemm16(int32_t device, int32_t M, int32_t N, int32_t K, int32_t reps, float* max_abs_err,
+                            float* ref_abs_max, float* avg_us_bf16, float* avg_us_f32);
 
 #ifdef __cplusplus
 }

@@ -1108,4 +1108,59 @@ int32_t q3a_selftest_gemm(int32_t device, int32_t M, int32_t N, int32_t K, int32
   Q3A_CATCH(e)
 }
 
+int32_t q3a_selftest_gemm16(int32_t device, int32_t M, int32_t N, int32_t K, int32_t reps, float* max_abs_err,
+                            float* ref_abs_max, float* avg_us_bf16, float* avg_us_f32) {
+  q3a_engine* e = nullptr;
+  Q3A_TRY(e)
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) fail("no HIP device available");
+  HIPCHK(hipSetDevice(device));
+  std::vector<float> X((size_t)M * K);
+  std::vector<uint16_t> W((size_t)N * K);
+  uint32_t st = 777u;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 65536.0f - 0.5f; };
+  auto trunc16 = [](float f) { uint32_t u; memcpy(&u, &f, 4); u &= 0xffff0000u; memcpy(&f, &u, 4); return f; };
+  for (auto& v : X) v = trunc16(rnd());  // bf16-representable activations: the bf16 copy is exact
+  for (auto& v : W) { float f = rnd(); uint32_t u; memcpy(&u, &f, 4); v = (uint16_t)(u >> 16); }
+  DevBuf dX, dX16, dW, dY, dR;
+  dX.ensure(X.size() * 4); dX16.ensure(X.size() * 2); dW.ensure(W.size() * 2); dY.ensure((size_t)M * N * 4); dR.ensure((size_t)M * N * 4);
+  HIPCHK(hipMemcpy(dX.p, X.data(), X.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dW.p, W.data(), W.size() * 2, hipMemcpyHostToDevice));
+  KCHK(launch_to_bf16(dX.as<float>(), dX16.as<uint16_t>(), X.size(), nullptr));
+  GemmEpilogue ep; ep.out = dY.as<float>(); ep.ldo = N;
+  KCHK(launch_gemm16(dX16.as<uint16_t>(), K, dW.as<uint16_t>(), M, N, K, ep, false, nullptr));
+  launch_gemm_ref(dX.as<float>(), dW.as<uint16_t>(), dR.as<float>(), M, N, K, nullptr);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipGetLastError());
+  std::vector<float> Y((size_t)M * N), R((size_t)M * N);
+  HIPCHK(hipMemcpy(Y.data(), dY.p, Y.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(R.data(), dR.p, R.size() * 4, hipMemcpyDeviceToHost));
+  float me = 0.f, rm = 0.f;
+  for (size_t i = 0; i < Y.size(); ++i) { me = std::max(me, std::fabs(Y[i] - R[i])); rm = std::max(rm, std::fabs(R[i])); }
+  if (max_abs_err) *max_abs_err = me;
+  if (ref_abs_max) *ref_abs_max = rm;
+  if (reps > 0) {
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    float ms = 0.f;
+    HIPCHK(hipEventRecord(a, nullptr));
+    for (int r = 0; r < reps; ++r) KCHK(launch_gemm16(dX16.as<uint16_t>(), K, dW.as<uint16_t>(), M, N, K, ep, false, nullptr));
+    HIPCHK(hipEventRecord(b, nullptr));
+    HIPCHK(hipEventSynchronize(b));
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    if (avg_us_bf16) *avg_us_bf16 = ms * 1000.f / reps;
+    HIPCHK(hipEventRecord(a, nullptr));
+    for (int r = 0; r < reps; ++r) KCHK(launch_gemm(dX.as<float>(), K, dW.as<uint16_t>(), M, N, K, ep, false, false, nullptr));
+    HIPCHK(hipEventRecord(b, nullptr));
+    HIPCHK(hipEventSynchronize(b));
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    if (avg_us_f32) *avg_us_f32 = ms * 1000.f / reps;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+  }
+  dX.release(); dX16.release(); dW.release(); dY.release(); dR.release();
+  Q3A_CATCH(e)
+}
+
 }  // extern "C"

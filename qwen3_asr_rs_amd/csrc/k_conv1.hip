@@ -16,7 +16,8 @@ constexpr int MAX_COUT = 512;  // weights + bias staged in LDS
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ mel, const int64_t* __restrict__ mel_off,
                                                     const int* __restrict__ n_frames, ChunkTable ct, int n_mels,
                                                     int chunk_frames, const float* __restrict__ w,
-                                                    const float* __restrict__ bias, int Cout, float* __restrict__ out) {
+                                                    const float* __restrict__ bias, int Cout, float* __restrict__ out,
+                                                    uint16_t* __restrict__ out16) {
   __shared__ float in_l[3][MAX_W + 2];     // three input rows, column index shifted by +1 (pad)
   __shared__ float w_l[MAX_COUT * 9];
   __shared__ float b_l[MAX_COUT];
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
   for (int i = tid; i < Cout * 9; i += 256) w_l[i] = w[i];
   for (int i = tid; i < Cout; i += 256) b_l[i] = bias ? bias[i] : 0.f;
   __syncthreads();
-  float* o = out + ((size_t)chunk * OH + oh) * OW * Cout;
+  const size_t obase = ((size_t)chunk * OH + oh) * OW * Cout;
   const int total = OW * Cout;
   for (int e = tid; e < total; e += 256) {
     const int ow = e / Cout, co = e - ow * Cout;
@@ -46,7 +47,9 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) acc += wp[kh * 3 + kw] * in_l[kh][ow * 2 + kw];  // (ow*2-1+kw)+1
-    o[e] = gelu_erf(acc);
+    const float g = gelu_erf(acc);
+    if (out16) out16[obase + e] = (uint16_t)f32_to_bf16_bits(g);  // default mode: bf16 map feeds conv2's LDS-DMA
+    else out[obase + e] = g;
   }
 }
 
@@ -54,13 +57,13 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
 
 const char* launch_conv1(const float* mel, const int64_t* mel_off, const int* n_frames, const ChunkTable& ct,
                          int n_chunks, int n_mels, int chunk_frames, const float* w, const float* b, int Cout,
-                         float* out, hipStream_t s) {
+                         float* out, hipStream_t s, uint16_t* out16) {
   if (n_chunks <= 0) return nullptr;
   if (chunk_frames > MAX_W) return "conv1: chunk_frames > 128 unsupported";
   if (Cout > MAX_COUT) return "conv1: more than 512 channels unsupported";
   const int OH = (n_mels - 1) / 2 + 1;
   hipLaunchKernelGGL(conv1_kernel, dim3(OH, n_chunks), dim3(256), 0, s, mel, mel_off, n_frames, ct, n_mels,
-                     chunk_frames, w, b, Cout, out);
+                     chunk_frames, w, b, Cout, out, out16);
   return nullptr;
 }
 

@@ -200,8 +200,15 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {  // registers 4*r4 .. 4*r4+3 are 4 consecutive head dims
         const int d = dt * 32 + 8 * r4 + 4 * half;
-        *reinterpret_cast<float4*>(orow + d) =
-            make_float4(oacc[dt][4 * r4] * inv, oacc[dt][4 * r4 + 1] * inv, oacc[dt][4 * r4 + 2] * inv, oacc[dt][4 * r4 + 3] * inv);
+        const float4 v = make_float4(oacc[dt][4 * r4] * inv, oacc[dt][4 * r4 + 1] * inv, oacc[dt][4 * r4 + 2] * inv, oacc[dt][4 * r4 + 3] * inv);
+        if (a.o16) {  // bf16 output feeds the out/o projection GEMM's LDS-DMA
+          uint2 pk;
+          pk.x = pack_bf16x2(v.x, v.y);
+          pk.y = pack_bf16x2(v.z, v.w);
+          *reinterpret_cast<uint2*>(a.o16 + (size_t)(seg.q_row0 + qi) * a.o_rs + head * HD + d) = pk;
+        } else {
+          *reinterpret_cast<float4*>(orow + d) = v;
+        }
       }
   }
 }

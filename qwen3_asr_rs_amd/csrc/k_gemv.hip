@@ -24,9 +24,12 @@ namespace q3a {
 
 int gemv_rows_per_wave(const GemvArgs& a) {  // physical weight rows per wave
   const int logical = (a.mode == 2) ? a.N / 2 : a.N;
+  // tuning knobs for A/B runs (rows per wave for mid-size and small matrices); defaults are the measured best
+  static const int mid = [] { const char* e = getenv("Q3A_GEMV_PR_MID"); return e ? atoi(e) : 2; }();
+  static const int small = [] { const char* e = getenv("Q3A_GEMV_PR_SMALL"); return e ? atoi(e) : 1; }();
   if (logical >= 32768) return 4;
-  if (logical >= 4096 || a.mode == 2) return 2;
-  return 1;
+  if (logical >= 4096 || a.mode == 2) return (mid == 4 || mid == 2) ? mid : 2;
+  return (small == 1 || small == 2 || small == 4) ? small : 1;
 }
 int gemv_blocks(const GemvArgs& a) {
   const int pr = gemv_rows_per_wave(a);

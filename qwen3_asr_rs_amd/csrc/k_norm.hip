@@ -12,7 +12,7 @@ constexpr int MAX_V = 8;  // float4 per lane -> D <= 2048
 template <bool LN>
 __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                    const float* __restrict__ b, float* __restrict__ y, int rows, int D,
-                                                   float eps) {
+                                                   float eps, uint16_t* __restrict__ y16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -67,7 +67,14 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
         o.z = (v[i].z * rstd) * wv.z;
         o.w = (v[i].w * rstd) * wv.w;
       }
-      reinterpret_cast<float4*>(yr)[c] = o;
+      if (y16) {  // default mode: bf16 copy for the next GEMM's LDS-DMA
+        uint2 pk;
+        pk.x = pack_bf16x2(o.x, o.y);
+        pk.y = pack_bf16x2(o.z, o.w);
+        reinterpret_cast<uint2*>(y16 + (size_t)row * D)[c] = pk;
+      } else {
+        reinterpret_cast<float4*>(yr)[c] = o;
+      }
     }
   }
 }
@@ -93,16 +100,16 @@ __global__ void scatter_rows_kernel(const float* __restrict__ src, const int* __
 }  // namespace
 
 const char* launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps,
-                             hipStream_t s) {
+                             hipStream_t s, uint16_t* y16) {
   if (rows <= 0) return nullptr;
   if (D % 4 != 0 || D > MAX_V * 256) return "layernorm: D must be a multiple of 4 and <= 2048";
-  hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, y, rows, D, eps);
+  hipLaunchKernelGGL(norm_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, y, rows, D, eps, y16);
   return nullptr;
 }
-const char* launch_rmsnorm(const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s) {
+const char* launch_rmsnorm(const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s, uint16_t* y16) {
   if (rows <= 0) return nullptr;
   if (D % 4 != 0 || D > MAX_V * 256) return "rmsnorm: D must be a multiple of 4 and <= 2048";
-  hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, (const float*)nullptr, y, rows, D, eps);
+  hipLaunchKernelGGL(norm_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, (const float*)nullptr, y, rows, D, eps, y16);
   return nullptr;
 }
 const char* launch_gather_rows(const float* src, const int* row_idx, int n, int D, float* dst, hipStream_t s) {

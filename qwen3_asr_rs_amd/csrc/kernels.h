@@ -9,6 +9,7 @@ namespace q3a {
 // ---- GEMM (k_gemm.hip) -----------------------------------------------------------------------------
 struct GemmEpilogue {
   float* out = nullptr;          // [rows][ldo] fp32
+  uint16_t* out16 = nullptr;     // alternative bf16 output (k_gemm16.hip only): feeds the next GEMM's LDS-DMA directly
   int ldo = 0;
   const float* bias = nullptr;   // [N] or null
   int act = 0;                   // 0 none, 1 erf-GELU
@@ -24,6 +25,14 @@ const char* launch_gemm(const float* X, int lda, const uint16_t* W, int M, int N
 const char* launch_conv3x3s2_gemm(const float* X, int imgs, int H, int Wd, int C, const uint16_t* Wt, int Cout,
                                   const GemmEpilogue& ep, bool split, hipStream_t s);
 void launch_gemm_ref(const float* X, const uint16_t* W, float* Y, int M, int N, int K, hipStream_t s);
+// bf16-activation versions (k_gemm16.hip, default mode): both operands go HBM -> LDS with global_load_lds.
+const char* launch_gemm16(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
+                          bool glu, hipStream_t s);
+// zero_page: >= 128 B of zeros (padded filter taps read it)
+const char* launch_conv3x3s2_gemm16(const uint16_t* X, const uint16_t* zero_page, int imgs, int H, int Wd, int C,
+                                    const uint16_t* Wt, int Cout, const GemmEpilogue& ep, hipStream_t s);
+// fp32 -> bf16 (round to nearest even), n elements
+const char* launch_to_bf16(const float* x, uint16_t* y, size_t n, hipStream_t s);
 
 // ---- log-mel front end (k_mel.hip) -------------------------------------------------------------------
 struct MelBatch {
@@ -46,12 +55,13 @@ struct ChunkTable {
 // mel (128, F_b) blocks -> NHWC fp32 [chunk][64][W/2][Cout] = gelu(conv3x3 s2 p1 + bias), chunk zero-padded to `chunk_frames`
 const char* launch_conv1(const float* mel, const int64_t* mel_off, const int* n_frames, const ChunkTable& ct,
                          int n_chunks, int n_mels, int chunk_frames, const float* w /*[Cout][9]*/,
-                         const float* b, int Cout, float* out, hipStream_t s);
+                         const float* b, int Cout, float* out, hipStream_t s, uint16_t* out16 = nullptr);
 
 // ---- norms (k_norm.hip) ----------------------------------------------------------------------------------
 const char* launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps,
-                             hipStream_t s);
-const char* launch_rmsnorm(const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s);
+                             hipStream_t s, uint16_t* y16 = nullptr);  // y16 != null: write bf16 there instead of y
+const char* launch_rmsnorm(const float* x, const float* w, float* y, int rows, int D, float eps, hipStream_t s,
+                           uint16_t* y16 = nullptr);
 
 // ---- attention over independent segments (k_attn.hip) ------------------------------------------------------
 // One segment = a set of `len` queries/keys that attend to each other (encoder windows, non-causal) or a
@@ -68,6 +78,7 @@ struct AttnArgs {
   const float* q; int q_rs;
   const void* k; const void* v; int64_t kv_hs; int kv_rs;
   float* o; int o_rs;
+  uint16_t* o16;    // MFMA flash attention only: when non-null the output is written here as bf16 (same strides)
   const AttnSeg* segs; int n_segs; int max_len;
   int n_kv_heads;
   float scale_div;  // scores are divided by this (sqrt(head_dim)), as the reference does

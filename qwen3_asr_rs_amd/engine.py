@@ -204,6 +204,20 @@ class HipEngine:
         return out
 
 
+def selftest_gemm16(M: int, N: int, K: int, reps: int = 0, device: int = 0) -> dict:
+    """bf16-activation GEMM (global_load_lds path) vs the naive device reference; optional timing of both GEMMs."""
+    lib = _lib.load()
+    err, ref, t16, t32 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+    rc = lib.q3a_selftest_gemm16(device, M, N, K, reps, C.byref(err), C.byref(ref), C.byref(t16), C.byref(t32))
+    if rc != 0:
+        raise Q3aError((lib.q3a_last_error(None) or b"").decode())
+    flops = 2.0 * M * N * K
+    out = {"err": err.value, "ref_max": ref.value}
+    if reps > 0:
+        out.update(us_bf16=t16.value, us_f32=t32.value, tflops_bf16=flops / t16.value / 1e6, tflops_f32=flops / t32.value / 1e6)
+    return out
+
+
 def selftest_gemm(M: int, N: int, K: int, split: bool = False, device: int = 0) -> Tuple[float, float]:
     lib = _lib.load()
     err, ref = C.c_float(), C.c_float()
