@@ -119,6 +119,8 @@ struct q3a_engine {
   DevBuf dec_x, dec_ln, dec_qkv, dec_ctx, dec_act, kcache, vcache;
   DevBuf x_dec, d_pos, next_tok, out_ids, step_count, done, s_ln, s_qkv, s_ctx, s_act, logits, forced_tok, part_val, part_idx;
   DevBuf attn_pm, attn_pl, attn_po;
+  DevBuf enc_ctx16, dec_ctx16;  // opts.valu_attention in the default mode: bf16 copy of the fp32 attention context
+  DevBuf zero_page;  // 256 B of zeros: padded filter taps of the bf16 implicit-GEMM convolutions read it
   int part_stride = 0, attn_nsplit = 0;
   size_t kv_layer_elems = 0;
 
@@ -136,6 +138,9 @@ struct q3a_engine {
   bool precise() const { return opts.precise != 0; }
   bool kv_f32() const { return opts.precise != 0; }
   size_t kv_elem() const { return kv_f32() ? 4 : 2; }
+  // GEMM-input activations (conv maps, norm outputs, attention context, FFN hidden) are stored as bf16 in the default
+  // mode -- exactly the values the MFMA consumes -- and as fp32 in the precise mode (hi+lo split inside the GEMM)
+  size_t act_elem() const { return precise() ? 4 : 2; }
   template <typename T> const T* w(uint64_t off) const { return reinterpret_cast<const T*>(arena + off); }
   const float* wf(uint64_t off) const { return w<float>(off); }
   const uint16_t* wh(uint64_t off) const { return w<uint16_t>(off); }
@@ -147,6 +152,31 @@ struct q3a_engine {
     tap_bytes[name] = bytes;
     HIPCHK(hipMemcpyAsync(t.p, ptr, bytes, hipMemcpyDeviceToDevice, stream));
   }
+  // tap of an activation buffer that is bf16 in the default mode and fp32 in the precise mode: always read back as fp32
+  void tap_act(const char* name, const void* ptr, size_t elems) {
+    if (!opts.debug_taps || elems == 0) return;
+    if (precise()) return tap(name, ptr, elems * 4);
+    DevBuf& t = taps[name];
+    t.ensure(elems * 4);
+    tap_bytes[name] = elems * 4;
+    KCHK(launch_from_bf16((const uint16_t*)ptr, t.as<float>(), elems, stream));
+  }
+
+  // GEMM over an activation buffer: LDS-DMA bf16 kernel (k_gemm16.hip) in the default mode, fp32 hi+lo split kernel
+  // (k_gemm.hip) in the precise mode
+  void act_gemm(const DevBuf& x, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep, bool glu) {
+    if (precise()) KCHK(launch_gemm(x.as<float>(), lda, W, M, N, K, ep, glu, true, stream));
+    else KCHK(launch_gemm16(x.as<uint16_t>(), lda, W, M, N, K, ep, glu, stream));
+  }
+  void act_conv(const DevBuf& x, int imgs, int H, int Wd, int C, const uint16_t* W, int Cout, const GemmEpilogue& ep) {
+    if (precise()) KCHK(launch_conv3x3s2_gemm(x.as<float>(), imgs, H, Wd, C, W, Cout, ep, true, stream));
+    else KCHK(launch_conv3x3s2_gemm16(x.as<uint16_t>(), zero_page.as<uint16_t>(), imgs, H, Wd, C, W, Cout, ep, stream));
+  }
+  // point a GEMM epilogue / producer at an activation buffer in the mode's storage type
+  void act_out(GemmEpilogue& ep, const DevBuf& buf) const {
+    if (precise()) ep.out = buf.as<float>(); else ep.out16 = buf.as<uint16_t>();
+  }
+  uint16_t* act16(const DevBuf& buf) const { return precise() ? nullptr : buf.as<uint16_t>(); }
 
   // run fn() (which enqueues exactly one kernel class) optionally bracketed by events
   template <class F> void timed(int kclass, double bytes, F&& fn) {
@@ -188,6 +218,8 @@ struct q3a_engine {
     upload(dft, dftm, stream);
     upload(filt_t, filt, stream);
     upload(pos_emb, pe, stream);
+    zero_page.ensure(256);
+    HIPCHK(hipMemsetAsync(zero_page.p, 0, 256, stream));
     ensure_rope(8192);
     HIPCHK(hipStreamSynchronize(stream));
   }
@@ -316,28 +348,33 @@ struct q3a_engine {
     const int H3 = Dims::conv_len(H2), W3 = Dims::conv_len(W2);
     const bool sp = precise();
     const size_t nch = (size_t)total_chunks;
-    conv1.ensure(nch * H1 * W1 * C * 4);
-    conv2.ensure(nch * H2 * W2 * C * 4);
-    conv3.ensure(nch * H3 * W3 * C * 4);
+    const size_t ae = act_elem();
+    conv1.ensure(nch * H1 * W1 * C * ae);
+    conv2.ensure(nch * H2 * W2 * C * ae);
+    conv3.ensure(nch * H3 * W3 * C * ae);
     const size_t Tt = (size_t)total_T;
-    enc_x.ensure(Tt * D * 4); enc_ln.ensure(Tt * D * 4); enc_qkv.ensure(Tt * 3 * D * 4); enc_ctx.ensure(Tt * D * 4);
-    enc_ffn.ensure(Tt * Fn * 4); audio_embeds.ensure(Tt * d.enc_out * 4);
+    // the fp32 VALU attention (precise mode / opts.valu_attention) writes an fp32 context that is rounded afterwards
+    const bool valu_attn = sp || opts.valu_attention;
+    enc_x.ensure(Tt * D * 4); enc_ln.ensure(Tt * D * ae); enc_qkv.ensure(Tt * 3 * D * 4);
+    enc_ctx.ensure(Tt * D * (valu_attn ? 4 : ae));
+    if (valu_attn && !sp) enc_ctx16.ensure(Tt * D * 2);
+    enc_ffn.ensure(Tt * Fn * ae); audio_embeds.ensure(Tt * d.enc_out * 4);
 
     ChunkTable ct{d_chunk_utt.as<int>(), d_chunk_frame0.as<int>()};
     KCHK(launch_conv1(mel.as<float>(), d_mel_off.as<int64_t>(), d_n_frames.as<int>(), ct, total_chunks, d.n_mels,
-                      d.chunk_frames(), wf(L.conv1_w), wf(L.conv1_b), C, conv1.as<float>(), stream));
-    tap("conv1", conv1.p, nch * H1 * W1 * C * 4);
+                      d.chunk_frames(), wf(L.conv1_w), wf(L.conv1_b), C, conv1.as<float>(), stream, act16(conv1)));
+    tap_act("conv1", conv1.p, nch * H1 * W1 * C);
     {
       GemmEpilogue ep;
-      ep.out = conv2.as<float>(); ep.ldo = C; ep.bias = wf(L.conv2_b); ep.act = 1;
-      KCHK(launch_conv3x3s2_gemm(conv1.as<float>(), total_chunks, H1, W1, C, wh(L.conv2_w), C, ep, sp, stream));
-      tap("conv2", conv2.p, nch * H2 * W2 * C * 4);
+      act_out(ep, conv2); ep.ldo = C; ep.bias = wf(L.conv2_b); ep.act = 1;
+      act_conv(conv1, total_chunks, H1, W1, C, wh(L.conv2_w), C, ep);
+      tap_act("conv2", conv2.p, nch * H2 * W2 * C);
     }
     {
       GemmEpilogue ep;  // rows land as [chunk][t][f][c]  (audio_encoder.rs:132-133 permute fused away)
-      ep.out = conv3.as<float>(); ep.ldo = C; ep.bias = wf(L.conv3_b); ep.act = 1; ep.rowmap = conv3_rowmap.as<int>();
-      KCHK(launch_conv3x3s2_gemm(conv2.as<float>(), total_chunks, H2, W2, C, wh(L.conv3_w), C, ep, sp, stream));
-      tap("conv3", conv3.p, nch * H3 * W3 * C * 4);
+      act_out(ep, conv3); ep.ldo = C; ep.bias = wf(L.conv3_b); ep.act = 1; ep.rowmap = conv3_rowmap.as<int>();
+      act_conv(conv2, total_chunks, H2, W2, C, wh(L.conv3_w), C, ep);
+      tap_act("conv3", conv3.p, nch * H3 * W3 * C);
     }
     {
       GemmEpilogue ep;  // conv_out + positional embedding (restarting per chunk) + valid-token gather
@@ -345,47 +382,54 @@ struct q3a_engine {
       ep.bias = (arena_flags & kFlagConvOutBias) ? wf(L.conv_out_b) : nullptr;
       ep.rowmap = convout_rowmap.as<int>();
       ep.addend = pos_emb.as<float>(); ep.addend_period = W3;
-      KCHK(launch_gemm(conv3.as<float>(), H3 * C, wh(L.conv_out_w), total_chunks * W3, D, H3 * C, ep, false, sp, stream));
+      act_gemm(conv3, H3 * C, wh(L.conv_out_w), total_chunks * W3, D, H3 * C, ep, false);
       tap("enc_in", enc_x.p, Tt * D * 4);
     }
     AttnArgs at{};
     at.q = enc_qkv.as<float>(); at.q_rs = 3 * D;
     at.k = enc_qkv.as<float>() + D; at.v = enc_qkv.as<float>() + 2 * D; at.kv_hs = 64; at.kv_rs = 3 * D;
     at.o = enc_ctx.as<float>(); at.o_rs = D;
+    at.o16 = valu_attn ? nullptr : enc_ctx.as<uint16_t>();
     at.segs = enc_segs.as<AttnSeg>(); at.n_segs = (int)enc_segs_h.size(); at.max_len = enc_max_seg;
     at.n_kv_heads = d.enc_heads; at.scale_div = 8.0f;  // sqrt(64), layers.rs:161
+    const DevBuf& ctx_in = (valu_attn && !sp) ? enc_ctx16 : enc_ctx;  // what the out projection reads
     for (int li = 0; li < d.enc_layers; ++li) {
       const EncLayerOff& e = L.enc[li];
-      KCHK(launch_layernorm(enc_x.as<float>(), wf(e.ln1_w), wf(e.ln1_b), enc_ln.as<float>(), total_T, D, 1e-5f, stream));
+      KCHK(launch_layernorm(enc_x.as<float>(), wf(e.ln1_w), wf(e.ln1_b), enc_ln.as<float>(), total_T, D, 1e-5f, stream, act16(enc_ln)));
       {
         GemmEpilogue ep; ep.out = enc_qkv.as<float>(); ep.ldo = 3 * D; ep.bias = wf(e.qkv_b);
-        KCHK(launch_gemm(enc_ln.as<float>(), D, wh(e.qkv_w), total_T, 3 * D, D, ep, false, sp, stream));
+        act_gemm(enc_ln, D, wh(e.qkv_w), total_T, 3 * D, D, ep, false);
       }
-      if (sp || opts.valu_attention) KCHK(launch_attn_enc(at, stream)); else KCHK(launch_fattn_enc(at, stream));
+      if (valu_attn) {
+        KCHK(launch_attn_enc(at, stream));
+        if (!sp) KCHK(launch_to_bf16(enc_ctx.as<float>(), enc_ctx16.as<uint16_t>(), Tt * D, stream));
+      } else {
+        KCHK(launch_fattn_enc(at, stream));
+      }
       {
         GemmEpilogue ep; ep.out = enc_x.as<float>(); ep.ldo = D; ep.bias = wf(e.out_b); ep.resid = enc_x.as<float>();
-        KCHK(launch_gemm(enc_ctx.as<float>(), D, wh(e.out_w), total_T, D, D, ep, false, sp, stream));
+        act_gemm(ctx_in, D, wh(e.out_w), total_T, D, D, ep, false);
       }
-      KCHK(launch_layernorm(enc_x.as<float>(), wf(e.ln2_w), wf(e.ln2_b), enc_ln.as<float>(), total_T, D, 1e-5f, stream));
+      KCHK(launch_layernorm(enc_x.as<float>(), wf(e.ln2_w), wf(e.ln2_b), enc_ln.as<float>(), total_T, D, 1e-5f, stream, act16(enc_ln)));
       {
-        GemmEpilogue ep; ep.out = enc_ffn.as<float>(); ep.ldo = Fn; ep.bias = wf(e.fc1_b); ep.act = 1;
-        KCHK(launch_gemm(enc_ln.as<float>(), D, wh(e.fc1_w), total_T, Fn, D, ep, false, sp, stream));
+        GemmEpilogue ep; act_out(ep, enc_ffn); ep.ldo = Fn; ep.bias = wf(e.fc1_b); ep.act = 1;
+        act_gemm(enc_ln, D, wh(e.fc1_w), total_T, Fn, D, ep, false);
       }
       {
         GemmEpilogue ep; ep.out = enc_x.as<float>(); ep.ldo = D; ep.bias = wf(e.fc2_b); ep.resid = enc_x.as<float>();
-        KCHK(launch_gemm(enc_ffn.as<float>(), Fn, wh(e.fc2_w), total_T, D, Fn, ep, false, sp, stream));
+        act_gemm(enc_ffn, Fn, wh(e.fc2_w), total_T, D, Fn, ep, false);
       }
       if (li == 0) tap("enc_layer0", enc_x.p, Tt * D * 4);
     }
     tap("enc_last", enc_x.p, Tt * D * 4);
-    KCHK(launch_layernorm(enc_x.as<float>(), wf(L.ln_post_w), wf(L.ln_post_b), enc_ln.as<float>(), total_T, D, 1e-5f, stream));
+    KCHK(launch_layernorm(enc_x.as<float>(), wf(L.ln_post_w), wf(L.ln_post_b), enc_ln.as<float>(), total_T, D, 1e-5f, stream, act16(enc_ln)));
     {
-      GemmEpilogue ep; ep.out = enc_ctx.as<float>(); ep.ldo = D; ep.bias = wf(L.proj1_b); ep.act = 1;
-      KCHK(launch_gemm(enc_ln.as<float>(), D, wh(L.proj1_w), total_T, D, D, ep, false, sp, stream));
+      GemmEpilogue ep; act_out(ep, enc_ffn); ep.ldo = D; ep.bias = wf(L.proj1_b); ep.act = 1;  // enc_ffn doubles as the proj1 output
+      act_gemm(enc_ln, D, wh(L.proj1_w), total_T, D, D, ep, false);
     }
     {
       GemmEpilogue ep; ep.out = audio_embeds.as<float>(); ep.ldo = d.enc_out; ep.bias = wf(L.proj2_b);
-      KCHK(launch_gemm(enc_ctx.as<float>(), D, wh(L.proj2_w), total_T, d.enc_out, D, ep, false, sp, stream));
+      act_gemm(enc_ffn, D, wh(L.proj2_w), total_T, d.enc_out, D, ep, false);
     }
     tap("audio_embeds", audio_embeds.p, Tt * d.enc_out * 4);
     HIPCHK(hipGetLastError());
@@ -437,8 +481,10 @@ struct q3a_engine {
     upload(dec_segs, segs, stream);
     upload(d_pos, P, stream);
     const size_t Pt = (size_t)total_P, H = d.hidden;
-    dec_x.ensure(Pt * H * 4); dec_ln.ensure(Pt * H * 4); dec_qkv.ensure(Pt * d.qkv_dim() * 4);
-    dec_ctx.ensure(Pt * d.q_dim() * 4); dec_act.ensure(Pt * d.inter * 4);
+    const bool valu_attn = kv_f32() || opts.valu_attention;
+    dec_x.ensure(Pt * H * 4); dec_ln.ensure(Pt * H * act_elem()); dec_qkv.ensure(Pt * d.qkv_dim() * 4);
+    dec_ctx.ensure(Pt * d.q_dim() * (valu_attn ? 4 : act_elem())); dec_act.ensure(Pt * d.inter * act_elem());
+    if (valu_attn && !precise()) dec_ctx16.ensure(Pt * d.q_dim() * 2);
     kv_layer_elems = (size_t)b * d.n_kv * max_ctx * 128;
     kcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
     vcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
@@ -498,13 +544,16 @@ struct q3a_engine {
     at.o = dec_ctx.as<float>(); at.o_rs = QD; at.segs = dec_segs.as<AttnSeg>(); at.n_segs = B;
     at.max_len = *std::max_element(P.begin(), P.end()); at.n_kv_heads = d.n_kv;
     at.scale_div = sqrtf((float)d.head_dim);  // layers.rs:327-328
+    const bool valu_attn = kv_f32() || opts.valu_attention;
+    at.o16 = valu_attn ? nullptr : dec_ctx.as<uint16_t>();
+    const DevBuf& ctx_in = (valu_attn && !sp) ? dec_ctx16 : dec_ctx;  // what the o projection reads
     const bool qkv_bias = arena_flags & kFlagDecQkvBias, o_bias = arena_flags & kFlagDecOBias, mlp_bias = arena_flags & kFlagDecMlpBias;
     for (int li = 0; li < d.dec_layers; ++li) {
       const DecLayerOff& l = L.dec[li];
-      KCHK(launch_rmsnorm(dec_x.as<float>(), wf(l.in_ln), dec_ln.as<float>(), total_P, H, d.rms_eps, stream));
+      KCHK(launch_rmsnorm(dec_x.as<float>(), wf(l.in_ln), dec_ln.as<float>(), total_P, H, d.rms_eps, stream, act16(dec_ln)));
       {
         GemmEpilogue ep; ep.out = dec_qkv.as<float>(); ep.ldo = QKV; ep.bias = qkv_bias ? wf(l.qkv_b) : nullptr;
-        KCHK(launch_gemm(dec_ln.as<float>(), H, wh(l.qkv_w), total_P, QKV, H, ep, false, sp, stream));
+        act_gemm(dec_ln, H, wh(l.qkv_w), total_P, QKV, H, ep, false);
       }
       RopeKvArgs rk{};
       rk.qkv = dec_qkv.as<float>(); rk.row_seq = row_seq.as<int>(); rk.row_pos = row_pos.as<int>();
@@ -513,19 +562,24 @@ struct q3a_engine {
       rk.kcache = kc_layer(li); rk.vcache = vc_layer(li); rk.n_q = d.n_q; rk.n_kv = d.n_kv; rk.max_ctx = max_ctx;
       KCHK(launch_qknorm_rope_kv(rk, total_P, kv_f32(), stream));
       at.k = kc_layer(li); at.v = vc_layer(li);
-      if (kv_f32() || opts.valu_attention) KCHK(launch_attn_prefill(at, d.n_q / d.n_kv, kv_f32(), stream)); else KCHK(launch_fattn_prefill(at, d.n_q / d.n_kv, stream));
+      if (valu_attn) {
+        KCHK(launch_attn_prefill(at, d.n_q / d.n_kv, kv_f32(), stream));
+        if (!sp) KCHK(launch_to_bf16(dec_ctx.as<float>(), dec_ctx16.as<uint16_t>(), (size_t)total_P * QD, stream));
+      } else {
+        KCHK(launch_fattn_prefill(at, d.n_q / d.n_kv, stream));
+      }
       {
         GemmEpilogue ep; ep.out = dec_x.as<float>(); ep.ldo = H; ep.resid = dec_x.as<float>(); ep.bias = o_bias ? wf(l.o_b) : nullptr;
-        KCHK(launch_gemm(dec_ctx.as<float>(), QD, wh(l.o_w), total_P, H, QD, ep, false, sp, stream));
+        act_gemm(ctx_in, QD, wh(l.o_w), total_P, H, QD, ep, false);
       }
-      KCHK(launch_rmsnorm(dec_x.as<float>(), wf(l.post_ln), dec_ln.as<float>(), total_P, H, d.rms_eps, stream));
+      KCHK(launch_rmsnorm(dec_x.as<float>(), wf(l.post_ln), dec_ln.as<float>(), total_P, H, d.rms_eps, stream, act16(dec_ln)));
       {
-        GemmEpilogue ep; ep.out = dec_act.as<float>(); ep.ldo = I; ep.bias = mlp_bias ? wf(l.gu_b) : nullptr;
-        KCHK(launch_gemm(dec_ln.as<float>(), H, wh(l.gu_w), total_P, 2 * I, H, ep, true, sp, stream));
+        GemmEpilogue ep; act_out(ep, dec_act); ep.ldo = I; ep.bias = mlp_bias ? wf(l.gu_b) : nullptr;
+        act_gemm(dec_ln, H, wh(l.gu_w), total_P, 2 * I, H, ep, true);
       }
       {
         GemmEpilogue ep; ep.out = dec_x.as<float>(); ep.ldo = H; ep.resid = dec_x.as<float>(); ep.bias = mlp_bias ? wf(l.down_b) : nullptr;
-        KCHK(launch_gemm(dec_act.as<float>(), I, wh(l.down_w), total_P, H, I, ep, false, sp, stream));
+        act_gemm(dec_act, I, wh(l.down_w), total_P, H, I, ep, false);
       }
       if (li == 0) tap("dec_layer0", dec_x.p, (size_t)total_P * H * 4);
     }
@@ -721,7 +775,8 @@ struct q3a_engine {
                       &mel, &gmax, &d_chunk_utt, &d_chunk_frame0, &conv1, &conv2, &conv3, &conv3_rowmap, &convout_rowmap,
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
                       &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
-                      &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po};
+                      &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po,
+                      &enc_ctx16, &dec_ctx16, &zero_page};
     for (auto* b : bufs) b->release();
     for (auto& kv : taps) kv.second.release();
     if (own_arena && arena) (void)hipFree(arena);

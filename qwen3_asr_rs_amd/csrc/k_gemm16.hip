@@ -219,7 +219,20 @@ __global__ void to_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict
   }
 }
 
+__global__ void from_bf16_kernel(const uint16_t* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = bf16_bits_to_f32(x[i]);
+}
+
 }  // namespace
+
+const char* launch_from_bf16(const uint16_t* x, float* y, size_t n, hipStream_t s) {
+  if (n == 0) return nullptr;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(from_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, n);
+  return nullptr;
+}
 
 const char* launch_gemm16(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
                           bool glu, hipStream_t s) {

@@ -33,6 +33,8 @@ const char* launch_conv3x3s2_gemm16(const uint16_t* X, const uint16_t* zero_page
                                     const uint16_t* Wt, int Cout, const GemmEpilogue& ep, hipStream_t s);
 // fp32 -> bf16 (round to nearest even), n elements
 const char* launch_to_bf16(const float* x, uint16_t* y, size_t n, hipStream_t s);
+// bf16 -> fp32 (debug taps of bf16 intermediates)
+const char* launch_from_bf16(const uint16_t* x, float* y, size_t n, hipStream_t s);
 
 // ---- log-mel front end (k_mel.hip) -------------------------------------------------------------------
 struct MelBatch {

@@ -67,7 +67,8 @@ def _stage_check(model_dir, clips, precise, steps=4):
     eng.mel(clips)
     embeds = eng.encode()
     cat = lambda key, f=(lambda t: t): np.concatenate([f(r.taps[key]).contiguous().numpy().ravel() for r in res])
-    assert rel_l2(eng.debug_read("conv1"), cat("conv1", lambda t: t.permute(0, 2, 3, 1))) <= 1e-5   # fp32 VALU stage
+    # fp32 VALU stage; the default mode stores the map rounded to bf16 (what conv2's MFMA consumes): |err| <= 2^-9 |x|
+    assert rel_l2(eng.debug_read("conv1"), cat("conv1", lambda t: t.permute(0, 2, 3, 1))) <= (1e-5 if precise else 2.0 ** -9)
     assert rel_l2(eng.debug_read("conv2"), cat("conv2", lambda t: t.permute(0, 2, 3, 1))) <= tol["rel"]
     assert rel_l2(eng.debug_read("conv3"), cat("conv3", lambda t: t.permute(0, 3, 2, 1))) <= tol["rel"]
     for k in ("enc_in", "enc_layer0", "enc_last", "audio_embeds"):
