@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libq3asr_hip.so")
+# Q3A_LIB: load an A/B build of the same library (qwen3_asr_rs_amd/build.py, Q3A_BUILD_VARIANT) instead
+LIB_PATH = os.environ.get("Q3A_LIB") or os.path.join(HERE, "lib", "libq3asr_hip.so")
 
 # every symbol include/q3asr.h declares (tests check the exports against the header text)
 SYMBOLS = [

@@ -28,6 +28,15 @@ HEADERS = ["dev.h", "kernels.h", "model.h", "json.h", "host.h", os.path.join("..
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
+# A/B builds for kernel experiments: Q3A_BUILD_VARIANT=name Q3A_BUILD_DEFINES="-DX=1 ..." builds
+# lib/libq3asr_hip_<name>.so next to the product library (load it with Q3A_LIB=<path>, see _lib.py).
+_VARIANT = os.environ.get("Q3A_BUILD_VARIANT", "")
+if _VARIANT:
+    FLAGS = FLAGS + os.environ.get("Q3A_BUILD_DEFINES", "").split()
+    OBJ_DIR = OBJ_DIR + "_" + _VARIANT
+    LIB_PATH = os.path.join(LIB_DIR, f"libq3asr_hip_{_VARIANT}.so")
+    CLI_PATH = os.path.join(BIN_DIR, f"asr_{_VARIANT}")
+
 
 def _hash(paths) -> str:
     h = hashlib.sha1()

@@ -23,6 +23,22 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// 16 B of a weight stream that the kernel reads exactly once per launch: non-temporal load, so the stream does not
+// displace the activations and partials the next kernels re-read from L2 (measured: decode 80.9 -> 76.9 ms per 100
+// tokens at batch 1; -DQ3A_NT_STREAM=0 restores plain loads for A/B runs).
+#ifndef Q3A_NT_STREAM
+#define Q3A_NT_STREAM 1
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ uint4 ld_stream16(const void* p) {
+#if Q3A_NT_STREAM
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+#else
+  const u32x4_t v = *reinterpret_cast<const u32x4_t*>(p);
+#endif
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

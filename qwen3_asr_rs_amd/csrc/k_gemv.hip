@@ -94,6 +94,48 @@ __device__ __forceinline__ void attn_combined8(const GemvArgs& a, int b, int k, 
   }
 }
 
+// Single-sequence form of the merge: no table, no barrier.  The 16 lanes that share a head read that head's (m, l)
+// statistics themselves (same-address loads, one request) together with the partial outputs -- every load is
+// independent, one L2 round trip -- and rescale online over chunks of 4 splits.
+__device__ __forceinline__ void attn_merge8(const GemvArgs& a, int b, int k, float (&x)[8]) {
+  const int h = k >> 7, d = k & 127;
+  const int ns = a.attn_nsplit;
+  const int base = (b * a.attn_heads + h) * ns;
+  float M = -INFINITY, L = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = 0.f;
+  for (int sp0 = 0; sp0 < ns; sp0 += 4) {
+    float m[4], l[4];
+    float4 o0[4], o1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int sp = sp0 + j, spc = sp < ns ? sp : ns - 1;  // clamp the address, void the statistics
+      m[j] = a.attn_pm[base + spc];
+      l[j] = a.attn_pl[base + spc];
+      if (sp >= ns) m[j] = -INFINITY;
+      o0[j] = *reinterpret_cast<const float4*>(a.attn_po + (size_t)(base + spc) * 128 + d);
+      o1[j] = *reinterpret_cast<const float4*>(a.attn_po + (size_t)(base + spc) * 128 + d + 4);
+    }
+    const float Mn = fmaxf(fmaxf(M, fmaxf(m[0], m[1])), fmaxf(m[2], m[3]));
+    if (Mn == -INFINITY) continue;  // only empty splits so far
+    const float sc = (M == -INFINITY) ? 0.f : expf(M - Mn);
+    L *= sc;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] *= sc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float f = (m[j] == -INFINITY) ? 0.f : expf(m[j] - Mn);
+      L += l[j] * f;
+      x[0] += o0[j].x * f; x[1] += o0[j].y * f; x[2] += o0[j].z * f; x[3] += o0[j].w * f;
+      x[4] += o1[j].x * f; x[5] += o1[j].y * f; x[6] += o1[j].z * f; x[7] += o1[j].w * f;
+    }
+    M = Mn;
+  }
+  const float inv = 1.0f / L;  // split 0 always holds at least the current token
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] *= inv;
+}
+
 template <int PR>
 __device__ __forceinline__ void gemv_rows(const GemvArgs& a, int g, int (&prow)[PR]) {
 #pragma unroll
@@ -196,12 +238,24 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
     const int k = lane * 8 + it * 512;
 #pragma unroll
     for (int i = 0; i < PR; ++i)
-      wq[it][i] = (prow[i] >= 0 && k < K) ? *reinterpret_cast<const uint4*>(a.W + (size_t)prow[i] * K + k)
+      wq[it][i] = (prow[i] >= 0 && k < K) ? ld_stream16(a.W + (size_t)prow[i] * K + k)
                                           : make_uint4(0u, 0u, 0u, 0u);
   }
   // 2. this lane's slice of x
-  __shared__ AttnTables f_s;
-  if (a.attn_po) attn_scales(a, 1, f_s);  // wave-uniform branch (kernel argument)
+  __shared__ __attribute__((aligned(16))) float x_s[KI * 512];  // only the attention-merge input goes through LDS
+  if (a.attn_po) {  // wave-uniform branch (kernel argument): each wave merges a quarter of the vector, once per block
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+      const int k = lane * 8 + it * 512;
+      if ((it & 3) == wave && k < K) {
+        float v[8];
+        attn_merge8(a, 0, k, v);
+        *reinterpret_cast<float4*>(x_s + k) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(x_s + k + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+    __syncthreads();
+  }
   float x[KI][8];
   float ss = 0.f;
 #pragma unroll
@@ -209,7 +263,9 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
     const int k = lane * 8 + it * 512;
     if (k < K) {
       if (a.attn_po) {
-        attn_combined8(a, 0, k, f_s, x[it]);
+        const float4 v0 = *reinterpret_cast<const float4*>(x_s + k), v1 = *reinterpret_cast<const float4*>(x_s + k + 4);
+        x[it][0] = v0.x; x[it][1] = v0.y; x[it][2] = v0.z; x[it][3] = v0.w;
+        x[it][4] = v1.x; x[it][5] = v1.y; x[it][6] = v1.z; x[it][7] = v1.w;
       } else {
         const float4 v0 = *reinterpret_cast<const float4*>(a.x + k);
         const float4 v1 = *reinterpret_cast<const float4*>(a.x + k + 4);
@@ -241,7 +297,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
     } else if (k < K) {
 #pragma unroll
       for (int i = 0; i < PR; ++i) {
-        const uint4 w = prow[i] >= 0 ? *reinterpret_cast<const uint4*>(a.W + (size_t)prow[i] * K + k) : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 w = prow[i] >= 0 ? ld_stream16(a.W + (size_t)prow[i] * K + k) : make_uint4(0u, 0u, 0u, 0u);
         acc[i][0] = dot8(w, x[it], acc[i][0]);
       }
     }
@@ -271,7 +327,7 @@ __global__ __launch_bounds__(256) void gemvn_kernel(GemvArgs a) {
     const int k = lane * 8 + it * 512;
 #pragma unroll
     for (int i = 0; i < PR; ++i)
-      wq[it][i] = (prow[i] >= 0 && k < K) ? *reinterpret_cast<const uint4*>(a.W + (size_t)prow[i] * K + k)
+      wq[it][i] = (prow[i] >= 0 && k < K) ? ld_stream16(a.W + (size_t)prow[i] * K + k)
                                           : make_uint4(0u, 0u, 0u, 0u);
   }
   __shared__ AttnTables f_s;
@@ -328,7 +384,7 @@ __global__ __launch_bounds__(256) void gemvn_kernel(GemvArgs a) {
     uint4 w[PR];
 #pragma unroll
     for (int i = 0; i < PR; ++i)
-      w[i] = prow[i] >= 0 ? *reinterpret_cast<const uint4*>(a.W + (size_t)prow[i] * K + k) : make_uint4(0u, 0u, 0u, 0u);
+      w[i] = prow[i] >= 0 ? ld_stream16(a.W + (size_t)prow[i] * K + k) : make_uint4(0u, 0u, 0u, 0u);
     fma_all(w, k);
   }
 #pragma unroll
