@@ -40,15 +40,21 @@ template <> struct Frag16<float> {
   }
 };
 
-constexpr int DA_WAVES = 8;
+#ifndef Q3A_DA_WAVES
+#define Q3A_DA_WAVES 8
+#endif
+constexpr int DA_WAVES = Q3A_DA_WAVES;  // waves per workgroup; a split is always 128 keys
+#ifndef Q3A_DATTN_EXP
+#define Q3A_DATTN_EXP 0  // timing experiments of tools/launch_floor.hip only (wrong results when non-zero)
+#endif
 
 template <int GROUP, typename KVT>
 __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnArgs a) {
   constexpr int DPL = Frag16<KVT>::DPL;   // head dims per lane: 8 (bf16) / 4 (f32)
   constexpr int LPK = 128 / DPL;          // lanes per key: 16 / 32
   constexpr int KPI = 64 / LPK;           // keys per load instruction: 4 / 2
-  constexpr int NI = 16 / KPI;            // load instructions per wave: 4 / 8 (16 keys per wave)
-  constexpr int KEYS_PER_WAVE = KPI * NI; // 16
+  constexpr int NI = (128 / DA_WAVES) / KPI;  // load instructions per wave: 4 / 8 at 16 keys per wave
+  constexpr int KEYS_PER_WAVE = KPI * NI;     // 16 with 8 waves
   constexpr int KEYS_PER_SPLIT = KEYS_PER_WAVE * DA_WAVES;  // 128
   static_assert(KEYS_PER_SPLIT == (sizeof(KVT) == 2 ? DATTN_KEYS_PER_SPLIT_BF16 : DATTN_KEYS_PER_SPLIT_F32), "split size");
   __shared__ float q_s[GROUP][128];
@@ -59,52 +65,73 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   const int kvh = blockIdx.x, s = blockIdx.y, sp = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPK, kq = lane / LPK;
-  const int pos = a.pos[s];
   const int key_lo = sp * KEYS_PER_SPLIT;
   const size_t pbase = ((size_t)s * a.n_q + (size_t)kvh * GROUP) * a.nsplit + sp;  // + g * nsplit
+  const int qkv_dim = (a.n_q + 2 * a.n_kv) * 128;
+  const float* row = a.qkv + (size_t)s * qkv_dim;
+  KVT* kc = reinterpret_cast<KVT*>(a.kcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
+  KVT* vc = reinterpret_cast<KVT*>(a.vcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
+
+  // ---- everything that does not depend on `pos` is requested before pos itself is waited for: the cache rows are
+  // read unconditionally (rows at or beyond pos hold stale data and are masked below; the index is clamped to the
+  // allocation) and so are the new token's q/k/v rows -- one memory round trip instead of two ----
+  const int key_base = key_lo + wave * KEYS_PER_WAVE + kq;
+  uint4 kraw[NI], vraw[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int key = min(key_base + i * KPI, a.max_ctx - 1);
+#if (Q3A_DATTN_EXP & 2)
+    kraw[i] = make_uint4(key, 0u, 0u, 0u); vraw[i] = kraw[i];
+#else
+    kraw[i] = *reinterpret_cast<const uint4*>(kc + (size_t)key * 128 + sub * DPL);
+    vraw[i] = *reinterpret_cast<const uint4*>(vc + (size_t)key * 128 + sub * DPL);
+#endif
+  }
+  float x1 = 0.f, x2 = 0.f, nw1 = 0.f, nw2 = 0.f;
+  if (wave < GROUP + 2) {  // waves 0..GROUP-1: the q heads, GROUP: k, GROUP+1: v
+    const int r = wave < GROUP ? kvh * GROUP + wave : (wave == GROUP ? a.n_q + kvh : a.n_q + a.n_kv + kvh);
+    x1 = row[r * 128 + lane];
+    x2 = row[r * 128 + lane + 64];
+    if (wave <= GROUP) {
+      const float* nw = wave < GROUP ? a.q_norm : a.k_norm;
+      nw1 = nw[lane];
+      nw2 = nw[lane + 64];
+    }
+  }
+  const int pos = a.pos[s];
   if (key_lo > pos) {  // this split holds no key yet: statistics of an empty set, zeroed output
     if (tid < GROUP) { a.pm[pbase + (size_t)tid * a.nsplit] = -INFINITY; a.pl[pbase + (size_t)tid * a.nsplit] = 0.f; }
     if (tid < GROUP * 128) a.po[(pbase + (size_t)(tid >> 7) * a.nsplit) * 128 + (tid & 127)] = 0.f;
     return;
   }
   const bool owner = (pos - key_lo) < KEYS_PER_SPLIT;  // the new token lands in this split
-  const int qkv_dim = (a.n_q + 2 * a.n_kv) * 128;
-  const float* row = a.qkv + (size_t)s * qkv_dim;
-  KVT* kc = reinterpret_cast<KVT*>(a.kcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
-  KVT* vc = reinterpret_cast<KVT*>(a.vcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
-
-  const int key_base = key_lo + wave * KEYS_PER_WAVE + kq;
-  uint4 kraw[NI], vraw[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int key = key_base + i * KPI;
-    if (key < pos) {
-      kraw[i] = *reinterpret_cast<const uint4*>(kc + (size_t)key * 128 + sub * DPL);
-      vraw[i] = *reinterpret_cast<const uint4*>(vc + (size_t)key * 128 + sub * DPL);
-    } else {
-      kraw[i] = make_uint4(0u, 0u, 0u, 0u);
-      vraw[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-  }
 
   // ---- new token: q for the GROUP heads of this kv head; k/v only in the owning split ----
+  if (wave <= GROUP) {  // per-head RMSNorm + RoPE (dev.h head_norm_rope, with the norm weights already in flight)
+#if (Q3A_DATTN_EXP & 8)
+    const float ss = x1 * x1 + x2 * x2;
+#else
+    const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
+#endif
+    const float rstd = 1.0f / sqrtf(ss / 128.0f + a.eps);
+    const float n1 = (x1 * rstd) * nw1, n2 = (x2 * rstd) * nw2;
+#if (Q3A_DATTN_EXP & 1)
+    const float c = 1.0f + pos, sn = 0.5f;
+#else
+    const float c = a.cos_t[(size_t)pos * 64 + lane], sn = a.sin_t[(size_t)pos * 64 + lane];
+#endif
+    x1 = n1 * c + (-n2) * sn;
+    x2 = n2 * c + n1 * sn;
+  }
   if (wave < GROUP) {
-    const int h = kvh * GROUP + wave;
-    float x1 = row[h * 128 + lane], x2 = row[h * 128 + lane + 64];
-    head_norm_rope(x1, x2, a.q_norm, a.eps, a.cos_t, a.sin_t, pos, lane);
     q_s[wave][lane] = x1;
     q_s[wave][lane + 64] = x2;
   } else if (owner && wave == GROUP) {
-    const float* p = row + (a.n_q + kvh) * 128;
-    float x1 = p[lane], x2 = p[lane + 64];
-    head_norm_rope(x1, x2, a.k_norm, a.eps, a.cos_t, a.sin_t, pos, lane);
     KvIo<KVT>::store(kc + (size_t)pos * 128 + lane, x1);
     KvIo<KVT>::store(kc + (size_t)pos * 128 + lane + 64, x2);
     k_s[lane] = KvIo<KVT>::round(x1);
     k_s[lane + 64] = KvIo<KVT>::round(x2);
   } else if (owner && wave == GROUP + 1) {
-    const float* p = row + (a.n_q + a.n_kv + kvh) * 128;
-    const float x1 = p[lane], x2 = p[lane + 64];
     KvIo<KVT>::store(vc + (size_t)pos * 128 + lane, x1);
     KvIo<KVT>::store(vc + (size_t)pos * 128 + lane + 64, x2);
     v_s[lane] = KvIo<KVT>::round(x1);
@@ -159,6 +186,9 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
     if (key == pos) {
 #pragma unroll
       for (int e = 0; e < DPL; ++e) vf[e] = v_s[sub * DPL + e];
+    } else if (key > pos) {  // stale cache row (possibly NaN bits): p is 0 there, keep 0 * v finite
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) vf[e] = 0.f;
     }
 #pragma unroll
     for (int g = 0; g < GROUP; ++g) {
@@ -178,6 +208,11 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
       if (LPK == 16) acc[g][e] += __shfl_xor(acc[g][e], 16, 64);
       acc[g][e] += __shfl_xor(acc[g][e], 32, 64);
     }
+#if (Q3A_DATTN_EXP & 4)
+    if (wave == g && kq == 0) { const size_t pi = pbase + (size_t)g * a.nsplit; a.pm[pi] = mw[g]; a.pl[pi] = lw[g];
+      for (int e = 0; e < DPL; ++e) a.po[pi * 128 + sub * DPL + e] = acc[g][e]; }
+    if (g == GROUP - 1) return;
+#endif
     if (lane == 0) { cm[wave][g] = mw[g]; cl[wave][g] = lw[g]; }
     if (kq == 0) {
 #pragma unroll

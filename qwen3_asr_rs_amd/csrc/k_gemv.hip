@@ -20,6 +20,10 @@
 #include "dev.h"
 #include "kernels.h"
 
+#ifndef Q3A_GEMV_XFIRST
+#define Q3A_GEMV_XFIRST 1
+#endif
+
 namespace q3a {
 
 int gemv_rows_per_wave(const GemvArgs& a) {  // physical weight rows per wave
@@ -187,8 +191,8 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int g, const in
       int ix = am_i[0][tid];
       for (int w = 1; w < 4; ++w)
         if (am_v[w][tid] > v || (am_v[w][tid] == v && am_i[w][tid] < ix)) { v = am_v[w][tid]; ix = am_i[w][tid]; }
-      a.part_val[(size_t)tid * a.part_stride + blockIdx.x] = v;
-      a.part_idx[(size_t)tid * a.part_stride + blockIdx.x] = ix;
+      a.part_val[(size_t)tid * a.part_stride + (g >> 2)] = v;
+      a.part_idx[(size_t)tid * a.part_stride + (g >> 2)] = ix;
     }
     return;
   }
@@ -222,15 +226,35 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int g, const in
 }
 
 // ---- NB == 1: x lives in registers (KI k-iterations of 512 columns, K <= 512*KI) ---------------------
-template <int PR, int PF, int KI>
+template <int PR, int PF, int KI, bool XFIRST>
 __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   __shared__ float am_v[4][1];
   __shared__ int am_i[4][1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
+  // (an XCD-contiguous block -> row remap, so that each output line is dirtied in one L2 only, measured 0.6 % slower)
   const int g = blockIdx.x * 4 + wave;
   int prow[PR];
   gemv_rows<PR>(a, g, prow);
+  // 0. RMSNorm-fused launches (XFIRST): x and the norm weight (L2 hits) are requested ahead of the HBM stream --
+  //    loads return in order, so they are back, squared and scaled long before the first weight chunk lands
+  //    (measured -0.2 us; without a norm the extra live registers cost more than they save: +0.2..0.4 us)
+  constexpr bool XF = Q3A_GEMV_XFIRST && XFIRST && KI <= 6;
+  float4 xr[XF ? KI : 1][2], nr[XF ? KI : 1][2];
+  if (XF && !a.attn_po) {
+#pragma unroll
+    for (int it = 0; it < (XF ? KI : 0); ++it) {
+      const int k = lane * 8 + it * 512;
+      if (k < K) {
+        xr[it][0] = *reinterpret_cast<const float4*>(a.x + k);
+        xr[it][1] = *reinterpret_cast<const float4*>(a.x + k + 4);
+        if (a.rms_w) {
+          nr[it][0] = *reinterpret_cast<const float4*>(a.rms_w + k);
+          nr[it][1] = *reinterpret_cast<const float4*>(a.rms_w + k + 4);
+        }
+      }
+    }
+  }
   // 1. weight prefetch
   uint4 wq[PF][PR];
 #pragma unroll
@@ -241,6 +265,8 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
       wq[it][i] = (prow[i] >= 0 && k < K) ? ld_stream16(a.W + (size_t)prow[i] * K + k)
                                           : make_uint4(0u, 0u, 0u, 0u);
   }
+  // (prefetching the layer's K/V cache into the XCD L2s from here was tried: -0.4 us on an isolated qkv+attention
+  //  pair, nothing measurable on the whole decode step, so it is not done)
   // 2. this lane's slice of x
   __shared__ __attribute__((aligned(16))) float x_s[KI * 512];  // only the attention-merge input goes through LDS
   if (a.attn_po) {  // wave-uniform branch (kernel argument): each wave merges a quarter of the vector, once per block
@@ -267,14 +293,14 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
         x[it][0] = v0.x; x[it][1] = v0.y; x[it][2] = v0.z; x[it][3] = v0.w;
         x[it][4] = v1.x; x[it][5] = v1.y; x[it][6] = v1.z; x[it][7] = v1.w;
       } else {
-        const float4 v0 = *reinterpret_cast<const float4*>(a.x + k);
-        const float4 v1 = *reinterpret_cast<const float4*>(a.x + k + 4);
+        const float4 v0 = XF ? xr[XF ? it : 0][0] : *reinterpret_cast<const float4*>(a.x + k);
+        const float4 v1 = XF ? xr[XF ? it : 0][1] : *reinterpret_cast<const float4*>(a.x + k + 4);
         x[it][0] = v0.x; x[it][1] = v0.y; x[it][2] = v0.z; x[it][3] = v0.w;
         x[it][4] = v1.x; x[it][5] = v1.y; x[it][6] = v1.z; x[it][7] = v1.w;
       }
       if (a.rms_w) {
-        const float4 w0 = *reinterpret_cast<const float4*>(a.rms_w + k);
-        const float4 w1 = *reinterpret_cast<const float4*>(a.rms_w + k + 4);
+        const float4 w0 = XF ? nr[XF ? it : 0][0] : *reinterpret_cast<const float4*>(a.rms_w + k);
+        const float4 w1 = XF ? nr[XF ? it : 0][1] : *reinterpret_cast<const float4*>(a.rms_w + k + 4);
         const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ss += x[it][e] * x[it][e]; x[it][e] *= wv[e]; }
@@ -400,10 +426,15 @@ __global__ __launch_bounds__(256) void gemvn_kernel(GemvArgs a) {
 template <int PR, int PF>
 void launch1(const GemvArgs& a, hipStream_t s) {
   const dim3 grid(gemv_blocks(a)), block(256);
-  if (a.K <= 1024) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 2 ? PF : 2), 2>), grid, block, 0, s, a);
-  else if (a.K <= 2048) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 4 ? PF : 4), 4>), grid, block, 0, s, a);
-  else if (a.K <= 3072) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 6 ? PF : 6), 6>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 12 ? PF : 12), 12>), grid, block, 0, s, a);
+  if (a.rms_w && !a.attn_po && a.K <= 2048) {
+    if (a.K <= 1024) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 2 ? PF : 2), 2, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 4 ? PF : 4), 4, true>), grid, block, 0, s, a);
+    return;
+  }
+  if (a.K <= 1024) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 2 ? PF : 2), 2, false>), grid, block, 0, s, a);
+  else if (a.K <= 2048) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 4 ? PF : 4), 4, false>), grid, block, 0, s, a);
+  else if (a.K <= 3072) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 6 ? PF : 6), 6, false>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 12 ? PF : 12), 12, false>), grid, block, 0, s, a);
 }
 template <int NB, int PR, int PF>
 void launchn(const GemvArgs& a, hipStream_t s) {

@@ -1,3 +1,4 @@
+# A/B runs of bench.py (batch 1) across library variants / env settings: name then env assignments
 mkdir -p gpurun_out/ab
 run() { name=$1; shift; env "$@" python bench.py --no-cpu-baseline --steps 5 --warmup 2 > gpurun_out/ab/$name.log 2>&1; python - <<PY
 import json
@@ -7,9 +8,7 @@ if l:
 else: print("$name FAILED")
 PY
 }
-run base A=1
-run kernarg1 HIP_FORCE_DEV_KERNARG=1
-run kernarg0 HIP_FORCE_DEV_KERNARG=0
-run nt Q3A_LIB=$PWD/qwen3_asr_rs_amd/lib/libq3asr_hip_nt.so
-run nt_kernarg1 Q3A_LIB=$PWD/qwen3_asr_rs_amd/lib/libq3asr_hip_nt.so HIP_FORCE_DEV_KERNARG=1
-run base2 A=1
+L=$PWD/qwen3_asr_rs_amd/lib
+for v in "$@"; do
+  if [ "$v" = base ]; then run base A=1; else run $v Q3A_LIB=$L/libq3asr_hip_$v.so; fi
+done

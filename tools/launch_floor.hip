@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <vector>
 #include "k_gemv.hip"  // the product GEMV kernels, timed in the same harness (compile with -I qwen3_asr_rs_amd/csrc)
+#include "k_dattn.hip"
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -164,6 +165,57 @@ int main() {
           const char* e = q3a::launch_gemv(a, 1, s);
           if (e) printf("launch_gemv: %s\n", e);
         }, (double)N * K * 2)) return 1;
+  }
+  // decode attention (k_dattn.hip): 16 q heads / 8 kv heads, context 450 of 512, cold bf16 cache (cycled through W)
+  {
+    const int n_q = 16, n_kv = 8, max_ctx = 512, nsplit = 4;
+    float *qkv, *cs, *sn, *nw, *pm, *pl, *po;
+    int* pos;
+    CHK(hipMalloc(&qkv, 4096 * 4)); CHK(hipMalloc(&cs, 512 * 64 * 4)); CHK(hipMalloc(&sn, 512 * 64 * 4)); CHK(hipMalloc(&nw, 128 * 4));
+    CHK(hipMalloc(&pm, n_q * nsplit * 4)); CHK(hipMalloc(&pl, n_q * nsplit * 4)); CHK(hipMalloc(&po, n_q * nsplit * 128 * 4));
+    CHK(hipMalloc(&pos, 4));
+    CHK(hipMemset(qkv, 0, 4096 * 4)); CHK(hipMemset(cs, 0, 512 * 64 * 4)); CHK(hipMemset(sn, 0, 512 * 64 * 4)); CHK(hipMemset(nw, 0, 128 * 4));
+    const int p450 = 450;
+    CHK(hipMemcpy(pos, &p450, 4, hipMemcpyHostToDevice));
+    const size_t layer_elems = (size_t)n_kv * max_ctx * 128;  // bf16 elements of one layer's K (or V)
+    const int layers = 200;
+    if (time_graph("product decode_attn ctx=450 nsplit=4 (cold KV)", n, s, [&](int i) {
+          q3a::DecodeAttnArgs a{};
+          a.qkv = qkv; a.pos = pos; a.q_norm = nw; a.k_norm = nw; a.eps = 1e-6f; a.cos_t = cs; a.sin_t = sn;
+          a.kcache = W + (size_t)(i % layers) * layer_elems; a.vcache = W + (size_t)(layers + i % layers) * layer_elems;
+          a.pm = pm; a.pl = pl; a.po = po; a.nsplit = nsplit; a.n_q = n_q; a.n_kv = n_kv; a.max_ctx = max_ctx; a.scale_div = 11.3137f;
+          const char* e = q3a::launch_decode_attn(a, 1, false, s);
+          if (e) printf("launch_decode_attn: %s\n", e);
+        })) return 1;
+    // pair: qkv GEMV (optionally prefetching the layer's cache) followed by the attention that reads it
+    for (int pf = 0; pf < 1; ++pf) {
+      float* xin; int* sink;
+      CHK(hipMalloc(&xin, 4096 * 4)); CHK(hipMalloc(&sink, 4)); CHK(hipMemset(xin, 0, 4096 * 4));
+      const size_t wstride = (size_t)4096 * 1024;
+      if (time_graph(pf ? "pair qkv-GEMV(+KV prefetch) + decode_attn (cold KV)" : "pair qkv-GEMV + decode_attn (cold KV)", n / 2, s, [&](int i) {
+            void* kc = W + (size_t)(i % layers) * layer_elems;
+            void* vc = W + (size_t)(layers + i % layers) * layer_elems;
+            q3a::GemvArgs g{};
+            g.x = xin; g.ldx = 1024; g.rms_w = nw; g.eps = 1e-6f; g.W = W + (size_t)(2 * layers) * layer_elems + (size_t)(i % 64) * wstride;
+            g.N = 4096; g.K = 1024; g.mode = 0; g.out = qkv; g.ldo = 4096;
+            const char* e = q3a::launch_gemv(g, 1, s);
+            if (e) printf("launch_gemv: %s\n", e);
+            q3a::DecodeAttnArgs a{};
+            a.qkv = qkv; a.pos = pos; a.q_norm = nw; a.k_norm = nw; a.eps = 1e-6f; a.cos_t = cs; a.sin_t = sn;
+            a.kcache = kc; a.vcache = vc;
+            a.pm = pm; a.pl = pl; a.po = po; a.nsplit = nsplit; a.n_q = n_q; a.n_kv = n_kv; a.max_ctx = max_ctx; a.scale_div = 11.3137f;
+            e = q3a::launch_decode_attn(a, 1, false, s);
+            if (e) printf("launch_decode_attn: %s\n", e);
+          })) return 1;
+    }
+    if (time_graph("product decode_attn ctx=450 nsplit=4 (warm KV)", n, s, [&](int i) {
+          q3a::DecodeAttnArgs a{};
+          a.qkv = qkv; a.pos = pos; a.q_norm = nw; a.k_norm = nw; a.eps = 1e-6f; a.cos_t = cs; a.sin_t = sn;
+          a.kcache = W; a.vcache = W + layer_elems;
+          a.pm = pm; a.pl = pl; a.po = po; a.nsplit = nsplit; a.n_q = n_q; a.n_kv = n_kv; a.max_ctx = max_ctx; a.scale_div = 11.3137f;
+          const char* e = q3a::launch_decode_attn(a, 1, false, s);
+          if (e) printf("launch_decode_attn: %s\n", e);
+        })) return 1;
   }
   // eager (no graph) chain for comparison
   {
