@@ -20,9 +20,6 @@
 #include "dev.h"
 #include "kernels.h"
 
-#ifndef Q3A_GEMV_XFIRST
-#define Q3A_GEMV_XFIRST 1
-#endif
 
 namespace q3a {
 
@@ -31,7 +28,7 @@ int gemv_rows_per_wave(const GemvArgs& a) {  // physical weight rows per wave
   // tuning knobs for A/B runs (rows per wave for mid-size and small matrices); defaults are the measured best
   static const int mid = [] { const char* e = getenv("Q3A_GEMV_PR_MID"); return e ? atoi(e) : 2; }();
   static const int small = [] { const char* e = getenv("Q3A_GEMV_PR_SMALL"); return e ? atoi(e) : 1; }();
-  if (logical >= 32768) return 4;
+  if (logical >= 32768 && a.K <= 2048) return 4;
   if (logical >= 4096 || a.mode == 2) return (mid == 4 || mid == 2) ? mid : 2;
   return (small == 1 || small == 2 || small == 4) ? small : 1;
 }
@@ -226,113 +223,139 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int g, const in
 }
 
 // ---- NB == 1: x lives in registers (KI k-iterations of 512 columns, K <= 512*KI) ---------------------
-template <int PR, int PF, int KI, bool XFIRST>
+// Straight-line by construction: RMS (norm fused) and ATTN (x = merged attention partials) are template flags and no
+// load sits under a lane-divergent branch -- out-of-range rows / columns are clamped to valid addresses and voided
+// arithmetically.  (With `row < N ? load : 0` guards hipcc put every weight load into its own exec-masked block with
+// an s_waitcnt vmcnt(0) between them: half of the stream was only requested after the other half had landed.)
+template <int PR, int KI, bool RMS, bool ATTN>
 __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   __shared__ float am_v[4][1];
   __shared__ int am_i[4][1];
+  __shared__ __attribute__((aligned(16))) float x_s[ATTN ? KI * 512 : 4];  // only the attention merge goes through LDS
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
   // (an XCD-contiguous block -> row remap, so that each output line is dirtied in one L2 only, measured 0.6 % slower)
   const int g = blockIdx.x * 4 + wave;
   int prow[PR];
   gemv_rows<PR>(a, g, prow);
-  // 0. RMSNorm-fused launches (XFIRST): x and the norm weight (L2 hits) are requested ahead of the HBM stream --
-  //    loads return in order, so they are back, squared and scaled long before the first weight chunk lands
-  //    (measured -0.2 us; without a norm the extra live registers cost more than they save: +0.2..0.4 us)
-  constexpr bool XF = Q3A_GEMV_XFIRST && XFIRST && KI <= 6;
-  float4 xr[XF ? KI : 1][2], nr[XF ? KI : 1][2];
-  if (XF && !a.attn_po) {
+  bool kin[KI];
+  int kk[KI];
 #pragma unroll
-    for (int it = 0; it < (XF ? KI : 0); ++it) {
-      const int k = lane * 8 + it * 512;
-      if (k < K) {
-        xr[it][0] = *reinterpret_cast<const float4*>(a.x + k);
-        xr[it][1] = *reinterpret_cast<const float4*>(a.x + k + 4);
-        if (a.rms_w) {
-          nr[it][0] = *reinterpret_cast<const float4*>(a.rms_w + k);
-          nr[it][1] = *reinterpret_cast<const float4*>(a.rms_w + k + 4);
-        }
-      }
-    }
-  }
-  // 1. weight prefetch
-  uint4 wq[PF][PR];
-#pragma unroll
-  for (int it = 0; it < PF; ++it) {
+  for (int it = 0; it < KI; ++it) {
     const int k = lane * 8 + it * 512;
-#pragma unroll
-    for (int i = 0; i < PR; ++i)
-      wq[it][i] = (prow[i] >= 0 && k < K) ? ld_stream16(a.W + (size_t)prow[i] * K + k)
-                                          : make_uint4(0u, 0u, 0u, 0u);
+    kin[it] = k < K;
+    kk[it] = kin[it] ? k : 0;
   }
-  // (prefetching the layer's K/V cache into the XCD L2s from here was tried: -0.4 us on an isolated qkv+attention
-  //  pair, nothing measurable on the whole decode step, so it is not done)
-  // 2. this lane's slice of x
-  __shared__ __attribute__((aligned(16))) float x_s[KI * 512];  // only the attention-merge input goes through LDS
-  if (a.attn_po) {  // wave-uniform branch (kernel argument): each wave merges a quarter of the vector, once per block
+  float4 xr[KI][2], nr[RMS ? KI : 1][2];
+  uint4 wq[KI][PR];
+  auto request_x = [&]() {  // L2 hits
+    if (ATTN) return;
 #pragma unroll
     for (int it = 0; it < KI; ++it) {
-      const int k = lane * 8 + it * 512;
-      if ((it & 3) == wave && k < K) {
+      xr[it][0] = *reinterpret_cast<const float4*>(a.x + kk[it]);
+      xr[it][1] = *reinterpret_cast<const float4*>(a.x + kk[it] + 4);
+      if (RMS) {
+        nr[it][0] = *reinterpret_cast<const float4*>(a.rms_w + kk[it]);
+        nr[it][1] = *reinterpret_cast<const float4*>(a.rms_w + kk[it] + 4);
+      }
+    }
+  };
+  auto request_w = [&]() {  // the HBM stream: all KI * PR chunks of the wave's rows in flight at once
+#pragma unroll
+    for (int it = 0; it < KI; ++it)
+#pragma unroll
+      for (int i = 0; i < PR; ++i) {
+        const int row = prow[i] >= 0 ? prow[i] : a.N - 1;
+        wq[it][i] = ld_stream16(a.W + (size_t)row * K + kk[it]);
+      }
+  };
+  // Loads return in order.  With a fused norm, x and the norm weight go first: they are back, squared and scaled long
+  // before the first weight chunk lands (-0.2 us).  Without one the weights go first (x-first measured +0.2..0.4 us).
+  if (RMS) { request_x(); request_w(); } else { request_w(); request_x(); }
+  // epilogue operands (bias, residual) ride behind the stream instead of costing an L2 round trip at the very end
+  float bv[PR], rv[PR];
+#pragma unroll
+  for (int i = 0; i < PR; ++i) {
+    const int n = prow[i] >= 0 ? prow[i] : 0;
+    bv[i] = a.bias ? a.bias[n] : 0.f;
+    rv[i] = a.mode == 1 ? a.resid[n] : 0.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);  // every request is issued before anything is waited for
+  if (ATTN) {  // each wave merges a quarter of the vector, once per block
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+      if ((it & 3) == wave && kin[it]) {
         float v[8];
-        attn_merge8(a, 0, k, v);
-        *reinterpret_cast<float4*>(x_s + k) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(x_s + k + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        attn_merge8(a, 0, kk[it], v);
+        *reinterpret_cast<float4*>(x_s + kk[it]) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(x_s + kk[it] + 4) = make_float4(v[4], v[5], v[6], v[7]);
       }
     }
     __syncthreads();
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+      xr[it][0] = *reinterpret_cast<const float4*>(x_s + kk[it]);
+      xr[it][1] = *reinterpret_cast<const float4*>(x_s + kk[it] + 4);
+    }
   }
   float x[KI][8];
   float ss = 0.f;
 #pragma unroll
   for (int it = 0; it < KI; ++it) {
-    const int k = lane * 8 + it * 512;
-    if (k < K) {
-      if (a.attn_po) {
-        const float4 v0 = *reinterpret_cast<const float4*>(x_s + k), v1 = *reinterpret_cast<const float4*>(x_s + k + 4);
-        x[it][0] = v0.x; x[it][1] = v0.y; x[it][2] = v0.z; x[it][3] = v0.w;
-        x[it][4] = v1.x; x[it][5] = v1.y; x[it][6] = v1.z; x[it][7] = v1.w;
-      } else {
-        const float4 v0 = XF ? xr[XF ? it : 0][0] : *reinterpret_cast<const float4*>(a.x + k);
-        const float4 v1 = XF ? xr[XF ? it : 0][1] : *reinterpret_cast<const float4*>(a.x + k + 4);
-        x[it][0] = v0.x; x[it][1] = v0.y; x[it][2] = v0.z; x[it][3] = v0.w;
-        x[it][4] = v1.x; x[it][5] = v1.y; x[it][6] = v1.z; x[it][7] = v1.w;
-      }
-      if (a.rms_w) {
-        const float4 w0 = XF ? nr[XF ? it : 0][0] : *reinterpret_cast<const float4*>(a.rms_w + k);
-        const float4 w1 = XF ? nr[XF ? it : 0][1] : *reinterpret_cast<const float4*>(a.rms_w + k + 4);
-        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const float4 v0 = xr[it][0], v1 = xr[it][1];
+    const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ss += x[it][e] * x[it][e]; x[it][e] *= wv[e]; }
-      }
-    } else {
+    for (int e = 0; e < 8; ++e) x[it][e] = kin[it] ? xv[e] : 0.f;  // columns beyond K contribute nothing
+    if (RMS) {
+      const float4 w0 = nr[it][0], w1 = nr[it][1];
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[it][e] = 0.f;
+      for (int e = 0; e < 8; ++e) { ss += x[it][e] * x[it][e]; x[it][e] *= wv[e]; }
     }
   }
-  // 3. dot products
   float acc[PR][1];
 #pragma unroll
   for (int i = 0; i < PR; ++i) acc[i][0] = 0.f;
 #pragma unroll
-  for (int it = 0; it < KI; ++it) {
-    const int k = lane * 8 + it * 512;
-    if (it < PF) {
+  for (int it = 0; it < KI; ++it)
 #pragma unroll
-      for (int i = 0; i < PR; ++i) acc[i][0] = dot8(wq[it < PF ? it : 0][i], x[it], acc[i][0]);
-    } else if (k < K) {
-#pragma unroll
-      for (int i = 0; i < PR; ++i) {
-        const uint4 w = prow[i] >= 0 ? ld_stream16(a.W + (size_t)prow[i] * K + k) : make_uint4(0u, 0u, 0u, 0u);
-        acc[i][0] = dot8(w, x[it], acc[i][0]);
-      }
-    }
-  }
+    for (int i = 0; i < PR; ++i) acc[i][0] = dot8(wq[it][i], x[it], acc[i][0]);
   float rstd = 1.0f;
-  if (a.rms_w) rstd = 1.0f / sqrtf(wave_sum_fast(ss) / (float)K + a.eps);  // a wave covers all of K
+  if (RMS) rstd = 1.0f / sqrtf(wave_sum_fast(ss) / (float)K + a.eps);  // a wave covers all of K
 #pragma unroll
-  for (int i = 0; i < PR; ++i) acc[i][0] = wave_sum_fast(acc[i][0]) * rstd;
-  gemv_epilogue<1, PR>(a, g, prow, acc, am_v, am_i);
+  for (int i = 0; i < PR; ++i) acc[i][0] = wave_sum_fast(acc[i][0]) * rstd + bv[i];
+  // epilogue (bias already added; acc is valid on every lane)
+  if (a.mode == 3) {  // logits + argmax partial (first-index tie-break: rows ascend with i, wave, block)
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < PR; ++i) {
+      if (prow[i] < 0) continue;
+      if (lane == 0 && a.out) a.out[prow[i]] = acc[i][0];
+      if (acc[i][0] > best) { best = acc[i][0]; bi = prow[i]; }
+    }
+    if (lane == 0) { am_v[wave][0] = best; am_i[wave][0] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float v = am_v[0][0];
+      int ix = am_i[0][0];
+      for (int w = 1; w < 4; ++w)
+        if (am_v[w][0] > v || (am_v[w][0] == v && am_i[w][0] < ix)) { v = am_v[w][0]; ix = am_i[w][0]; }
+      a.part_val[blockIdx.x] = v;
+      a.part_idx[blockIdx.x] = ix;
+    }
+    return;
+  }
+  if (lane != 0) return;
+  if (a.mode != 2) {
+#pragma unroll
+    for (int i = 0; i < PR; ++i)
+      if (prow[i] >= 0) a.out[prow[i]] = acc[i][0] + rv[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i + 1 < PR; i += 2)
+      if (prow[i] >= 0) a.out[g * (PR / 2) + (i >> 1)] = silu_f(acc[i][0]) * acc[i + 1][0];
+  }
 }
 
 // ---- NB in {2, 4}: x staged through LDS once per workgroup ---------------------------------------------
@@ -423,18 +446,20 @@ __global__ __launch_bounds__(256) void gemvn_kernel(GemvArgs a) {
   gemv_epilogue<NB, PR>(a, g, prow, acc, am_v, am_i);
 }
 
-template <int PR, int PF>
-void launch1(const GemvArgs& a, hipStream_t s) {
+template <int PR, int KI>
+void launch1k(const GemvArgs& a, hipStream_t s) {
   const dim3 grid(gemv_blocks(a)), block(256);
-  if (a.rms_w && !a.attn_po && a.K <= 2048) {
-    if (a.K <= 1024) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 2 ? PF : 2), 2, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 4 ? PF : 4), 4, true>), grid, block, 0, s, a);
-    return;
+  if (a.attn_po) hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, true>), grid, block, 0, s, a);
+  else if (a.rms_w) hipLaunchKernelGGL((gemv1_kernel<PR, KI, true, false>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, false>), grid, block, 0, s, a);
+}
+template <int PR>
+void launch1(const GemvArgs& a, hipStream_t s) {
+  if (a.K <= 1024) launch1k<PR, 2>(a, s);
+  else if (a.K <= 2048) launch1k<PR, 4>(a, s);
+  else if constexpr (PR < 4) {  // gemv_rows_per_wave keeps 4 rows per wave to K <= 2048 (registers)
+    if (a.K <= 3072) launch1k<PR, 6>(a, s); else launch1k<PR, 12>(a, s);
   }
-  if (a.K <= 1024) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 2 ? PF : 2), 2, false>), grid, block, 0, s, a);
-  else if (a.K <= 2048) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 4 ? PF : 4), 4, false>), grid, block, 0, s, a);
-  else if (a.K <= 3072) hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 6 ? PF : 6), 6, false>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((gemv1_kernel<PR, (PF < 12 ? PF : 12), 12, false>), grid, block, 0, s, a);
 }
 template <int NB, int PR, int PF>
 void launchn(const GemvArgs& a, hipStream_t s) {
@@ -450,6 +475,7 @@ const char* launch_gemv(const GemvArgs& a0, int NB, hipStream_t s) {
   if (a0.mode == 3 && (!a0.part_val || !a0.part_idx || gemv_blocks(a0) > a0.part_stride))
     return "gemv: argmax partial buffer missing/too small";
   if (a0.attn_po && (a0.K % 128 != 0 || a0.K != a0.attn_heads * 128)) return "gemv: attention-partial input needs K = heads*128";
+  if (a0.attn_po && a0.rms_w) return "gemv: attention-partial input cannot be combined with a fused RMSNorm";
   if (a0.attn_po && (NB < 4 ? NB : 4) * a0.attn_heads * a0.attn_nsplit > ATTN_F_MAX) return "gemv: too many attention splits for the LDS scale table";
   const int pr = gemv_rows_per_wave(a0);
   const int nb_cap = (int)((64 * 1024) / ((size_t)a0.K * 4));  // rows of x that fit in 64 KiB of LDS
@@ -469,7 +495,7 @@ const char* launch_gemv(const GemvArgs& a0, int NB, hipStream_t s) {
     else if (nb >= 2 && nb_cap >= 2) nb = 2;
     else nb = 1;
     if (nb == 1) {
-      if (pr == 4) launch1<4, 2>(a, s); else if (pr == 2) launch1<2, 4>(a, s); else launch1<1, 12>(a, s);
+      if (pr == 4) launch1<4>(a, s); else if (pr == 2) launch1<2>(a, s); else launch1<1>(a, s);
     } else if (nb == 2) {
       if (pr == 4) launchn<2, 4, 2>(a, s); else if (pr == 2) launchn<2, 2, 4>(a, s); else launchn<2, 1, 6>(a, s);
     } else {
