@@ -119,6 +119,7 @@ struct q3a_engine {
   DevBuf dec_x, dec_ln, dec_qkv, dec_ctx, dec_act, kcache, vcache;
   DevBuf x_dec, d_pos, next_tok, out_ids, step_count, done, s_ln, s_qkv, s_ctx, s_act, logits, forced_tok, part_val, part_idx;
   DevBuf attn_pm, attn_pl, attn_po;
+  DevBuf rope_cur;  // [B][128] cos|sin row of each sequence's current position (kept by argmax_finalize for decode attention)
   DevBuf enc_ctx16, dec_ctx16;  // opts.valu_attention in the default mode: bf16 copy of the fp32 attention context
   DevBuf zero_page;  // 256 B of zeros: padded filter taps of the bf16 implicit-GEMM convolutions read it
   int part_stride = 0, attn_nsplit = 0;
@@ -488,6 +489,7 @@ struct q3a_engine {
     kv_layer_elems = (size_t)b * d.n_kv * max_ctx * 128;
     kcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
     vcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
+    rope_cur.ensure((size_t)b * 128 * 4);
     x_dec.ensure((size_t)b * H * 4); next_tok.ensure((size_t)b * 4); forced_tok.ensure((size_t)b * 4);
     out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
     s_ln.ensure((size_t)b * H * 4); s_qkv.ensure((size_t)b * d.qkv_dim() * 4); s_ctx.ensure((size_t)b * d.q_dim() * 4);
@@ -529,6 +531,7 @@ struct q3a_engine {
     f.V = V; f.next_tok = next_tok.as<int>(); f.out_ids = out_ids.as<int>();
     f.out_stride = max_new; f.step_count = step_count.as<int>(); f.pos = d_pos.as<int>(); f.advance = advance;
     f.done = done.as<uint8_t>(); f.embed = wh(L.embed); f.H = H; f.x_next = x_dec.as<float>(); f.eos0 = kEos0; f.eos1 = kEos1;
+    f.cos_t = rope_cos.as<float>(); f.sin_t = rope_sin.as<float>(); f.rope_cur = rope_cur.as<float>();
     timed(Q3A_KC_ARGMAX, 0, [&] { KCHK(launch_argmax_finalize(f, S, stream)); });
   }
 
@@ -616,7 +619,7 @@ struct q3a_engine {
     const bool gemv = S <= 4;
     DecodeAttnArgs da{};
     da.qkv = s_qkv.as<float>(); da.pos = d_pos.as<int>(); da.eps = d.rms_eps;
-    da.cos_t = rope_cos.as<float>(); da.sin_t = rope_sin.as<float>();
+    da.rope_cur = rope_cur.as<float>();
     da.pm = attn_pm.as<float>(); da.pl = attn_pl.as<float>(); da.po = attn_po.as<float>(); da.nsplit = attn_nsplit;
     da.n_q = d.n_q; da.n_kv = d.n_kv; da.max_ctx = max_ctx; da.scale_div = sqrtf((float)d.head_dim);
     for (int li = 0; li < d.dec_layers; ++li) {
@@ -776,7 +779,7 @@ struct q3a_engine {
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
                       &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
                       &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po,
-                      &enc_ctx16, &dec_ctx16, &zero_page};
+                      &enc_ctx16, &dec_ctx16, &zero_page, &rope_cur};
     for (auto* b : bufs) b->release();
     for (auto& kv : taps) kv.second.release();
     if (own_arena && arena) (void)hipFree(arena);

@@ -44,9 +44,6 @@ template <> struct Frag16<float> {
 #define Q3A_DA_WAVES 8
 #endif
 constexpr int DA_WAVES = Q3A_DA_WAVES;  // waves per workgroup; a split is always 128 keys
-#ifndef Q3A_DATTN_EXP
-#define Q3A_DATTN_EXP 0  // timing experiments of tools/launch_floor.hip only (wrong results when non-zero)
-#endif
 
 template <int GROUP, typename KVT>
 __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnArgs a) {
@@ -72,22 +69,11 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   KVT* kc = reinterpret_cast<KVT*>(a.kcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
   KVT* vc = reinterpret_cast<KVT*>(a.vcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
 
-  // ---- everything that does not depend on `pos` is requested before pos itself is waited for: the cache rows are
-  // read unconditionally (rows at or beyond pos hold stale data and are masked below; the index is clamped to the
-  // allocation) and so are the new token's q/k/v rows -- one memory round trip instead of two ----
-  const int key_base = key_lo + wave * KEYS_PER_WAVE + kq;
-  uint4 kraw[NI], vraw[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int key = min(key_base + i * KPI, a.max_ctx - 1);
-#if (Q3A_DATTN_EXP & 2)
-    kraw[i] = make_uint4(key, 0u, 0u, 0u); vraw[i] = kraw[i];
-#else
-    kraw[i] = *reinterpret_cast<const uint4*>(kc + (size_t)key * 128 + sub * DPL);
-    vraw[i] = *reinterpret_cast<const uint4*>(vc + (size_t)key * 128 + sub * DPL);
-#endif
-  }
-  float x1 = 0.f, x2 = 0.f, nw1 = 0.f, nw2 = 0.f;
+  // ---- one memory round trip: nothing below depends on a loaded value until everything has been requested.
+  // 1. the new token's q/k/v rows, the norm weights and the RoPE row of this position (L2 hits; the RoPE row sits at a
+  //    fixed address, written by the previous step's finalize) go first: loads return in order, so q is normalised,
+  //    rotated and in LDS while the cache rows are still in flight
+  float x1 = 0.f, x2 = 0.f, nw1 = 0.f, nw2 = 0.f, c = 0.f, sn = 0.f;
   if (wave < GROUP + 2) {  // waves 0..GROUP-1: the q heads, GROUP: k, GROUP+1: v
     const int r = wave < GROUP ? kvh * GROUP + wave : (wave == GROUP ? a.n_q + kvh : a.n_q + a.n_kv + kvh);
     x1 = row[r * 128 + lane];
@@ -96,8 +82,21 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
       const float* nw = wave < GROUP ? a.q_norm : a.k_norm;
       nw1 = nw[lane];
       nw2 = nw[lane + 64];
+      c = a.rope_cur[(size_t)s * 128 + lane];
+      sn = a.rope_cur[(size_t)s * 128 + 64 + lane];
     }
   }
+  // 2. the cache rows, unconditionally (rows at or beyond pos hold stale data and are masked below; the index is
+  //    clamped to the allocation)
+  const int key_base = key_lo + wave * KEYS_PER_WAVE + kq;
+  uint4 kraw[NI], vraw[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int key = min(key_base + i * KPI, a.max_ctx - 1);
+    kraw[i] = *reinterpret_cast<const uint4*>(kc + (size_t)key * 128 + sub * DPL);
+    vraw[i] = *reinterpret_cast<const uint4*>(vc + (size_t)key * 128 + sub * DPL);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   const int pos = a.pos[s];
   if (key_lo > pos) {  // this split holds no key yet: statistics of an empty set, zeroed output
     if (tid < GROUP) { a.pm[pbase + (size_t)tid * a.nsplit] = -INFINITY; a.pl[pbase + (size_t)tid * a.nsplit] = 0.f; }
@@ -107,20 +106,11 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   const bool owner = (pos - key_lo) < KEYS_PER_SPLIT;  // the new token lands in this split
 
   // ---- new token: q for the GROUP heads of this kv head; k/v only in the owning split ----
-  if (wave <= GROUP) {  // per-head RMSNorm + RoPE (dev.h head_norm_rope, with the norm weights already in flight)
-#if (Q3A_DATTN_EXP & 8)
-    const float ss = x1 * x1 + x2 * x2;
-#else
+  if (wave <= GROUP) {  // per-head RMSNorm + RoPE (as dev.h head_norm_rope)
     const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
-#endif
     const float rstd = 1.0f / sqrtf(ss / 128.0f + a.eps);
     const float n1 = (x1 * rstd) * nw1, n2 = (x2 * rstd) * nw2;
-#if (Q3A_DATTN_EXP & 1)
-    const float c = 1.0f + pos, sn = 0.5f;
-#else
-    const float c = a.cos_t[(size_t)pos * 64 + lane], sn = a.sin_t[(size_t)pos * 64 + lane];
-#endif
-    x1 = n1 * c + (-n2) * sn;
+    x1 = n1 * c + (-n2) * sn;  // rotate_half = cat(-x2, x1)
     x2 = n2 * c + n1 * sn;
   }
   if (wave < GROUP) {
@@ -208,11 +198,6 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
       if (LPK == 16) acc[g][e] += __shfl_xor(acc[g][e], 16, 64);
       acc[g][e] += __shfl_xor(acc[g][e], 32, 64);
     }
-#if (Q3A_DATTN_EXP & 4)
-    if (wave == g && kq == 0) { const size_t pi = pbase + (size_t)g * a.nsplit; a.pm[pi] = mw[g]; a.pl[pi] = lw[g];
-      for (int e = 0; e < DPL; ++e) a.po[pi * 128 + sub * DPL + e] = acc[g][e]; }
-    if (g == GROUP - 1) return;
-#endif
     if (lane == 0) { cm[wave][g] = mw[g]; cl[wave][g] = lw[g]; }
     if (kq == 0) {
 #pragma unroll

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __rest
 __global__ __launch_bounds__(1024) void argmax_finalize_kernel(FinalizeArgs a) {
   __shared__ float bv[16];
   __shared__ int bi[16];
-  __shared__ int tok_s;
+  __shared__ int tok_s, pos_s;
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* pv = a.part_val + (size_t)s * a.part_stride;
   const int* pi = a.part_idx + (size_t)s * a.part_stride;
@@ -130,10 +130,16 @@ __global__ __launch_bounds__(1024) void argmax_finalize_kernel(FinalizeArgs a) {
     const int sc = a.step_count[s];
     if (sc < a.out_stride) a.out_ids[(size_t)s * a.out_stride + sc] = idx;
     a.step_count[s] = sc + 1;
-    a.pos[s] += a.advance;
+    const int np = a.pos[s] + a.advance;
+    a.pos[s] = np;
+    pos_s = np;
     if (idx == a.eos0 || idx == a.eos1) a.done[s] = 1;
   }
   __syncthreads();
+  // RoPE row of the position the next decode step works at, at a fixed address: the attention kernels of that step
+  // request it together with q/k/v instead of after a dependent load of pos
+  if (a.rope_cur && tid < 128)
+    a.rope_cur[(size_t)s * 128 + tid] = tid < 64 ? a.cos_t[(size_t)pos_s * 64 + tid] : a.sin_t[(size_t)pos_s * 64 + tid - 64];
   const int tok = tok_s;
   const uint2* src = reinterpret_cast<const uint2*>(a.embed + (size_t)tok * a.H);
   float4* dst = reinterpret_cast<float4*>(a.x_next + (size_t)s * a.H);

@@ -145,9 +145,9 @@ struct DecodeAttnArgs {
   const float* qkv;            // [S][qkv_dim] fp32 (raw projections of the current token)
   const int* pos;              // [S] number of tokens already in the cache = position of the current token
   const float* q_norm; const float* k_norm; float eps;
-  const float* cos_t; const float* sin_t;
+  const float* rope_cur;       // [S][128]: cos (64) | sin (64) of position pos[s], maintained by launch_argmax_finalize
   void* kcache; void* vcache;  // this layer
-  float* pm; float* pl;        // [S][n_q][nsplit] partial softmax max / sum per key split
+  float* pm; float* pl;       // [S][n_q][nsplit] partial softmax max / sum per key split
   float* po;                   // [S][n_q][nsplit][128] unnormalised partial outputs
   int nsplit;                  // >= ceil(max_ctx / dattn_keys_per_split(kv_f32))
   int n_q, n_kv, max_ctx;
@@ -175,6 +175,8 @@ struct FinalizeArgs {
   const uint16_t* embed; int H;
   float* x_next;           // [S][H] embedding of the chosen token
   int eos0, eos1;
+  const float* cos_t; const float* sin_t;  // RoPE tables [max_pos][64]
+  float* rope_cur;         // [S][128] (written): cos | sin row of the updated pos[s] (DecodeAttnArgs::rope_cur); nullable
 };
 // block partials of logits [S][V] (GEMM decode path; the GEMV lm_head produces its own)
 const char* launch_argmax_partials(const float* logits, int V, int S, float* pval, int* pidx, int stride, int nblk,

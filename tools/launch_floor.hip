@@ -181,7 +181,7 @@ int main() {
     const int layers = 200;
     if (time_graph("product decode_attn ctx=450 nsplit=4 (cold KV)", n, s, [&](int i) {
           q3a::DecodeAttnArgs a{};
-          a.qkv = qkv; a.pos = pos; a.q_norm = nw; a.k_norm = nw; a.eps = 1e-6f; a.cos_t = cs; a.sin_t = sn;
+          a.qkv = qkv; a.pos = pos; a.q_norm = nw; a.k_norm = nw; a.eps = 1e-6f; a.rope_cur = cs;
           a.kcache = W + (size_t)(i % layers) * layer_elems; a.vcache = W + (size_t)(layers + i % layers) * layer_elems;
           a.pm = pm; a.pl = pl; a.po = po; a.nsplit = nsplit; a.n_q = n_q; a.n_kv = n_kv; a.max_ctx = max_ctx; a.scale_div = 11.3137f;
           const char* e = q3a::launch_decode_attn(a, 1, false, s);
@@ -201,7 +201,7 @@ int main() {
             const char* e = q3a::launch_gemv(g, 1, s);
             if (e) printf("launch_gemv: %s\n", e);
             q3a::DecodeAttnArgs a{};
-            a.qkv = qkv; a.pos = pos; a.q_norm = nw; a.k_norm = nw; a.eps = 1e-6f; a.cos_t = cs; a.sin_t = sn;
+            a.qkv = qkv; a.pos = pos; a.q_norm = nw; a.k_norm = nw; a.eps = 1e-6f; a.rope_cur = cs;
             a.kcache = kc; a.vcache = vc;
             a.pm = pm; a.pl = pl; a.po = po; a.nsplit = nsplit; a.n_q = n_q; a.n_kv = n_kv; a.max_ctx = max_ctx; a.scale_div = 11.3137f;
             e = q3a::launch_decode_attn(a, 1, false, s);
@@ -210,7 +210,7 @@ int main() {
     }
     if (time_graph("product decode_attn ctx=450 nsplit=4 (warm KV)", n, s, [&](int i) {
           q3a::DecodeAttnArgs a{};
-          a.qkv = qkv; a.pos = pos; a.q_norm = nw; a.k_norm = nw; a.eps = 1e-6f; a.cos_t = cs; a.sin_t = sn;
+          a.qkv = qkv; a.pos = pos; a.q_norm = nw; a.k_norm = nw; a.eps = 1e-6f; a.rope_cur = cs;
           a.kcache = W; a.vcache = W + layer_elems;
           a.pm = pm; a.pl = pl; a.po = po; a.nsplit = nsplit; a.n_q = n_q; a.n_kv = n_kv; a.max_ctx = max_ctx; a.scale_div = 11.3137f;
           const char* e = q3a::launch_decode_attn(a, 1, false, s);
