@@ -16,6 +16,8 @@
 //   * the im2col view of the 3x3/s2/p1 convolutions reads padded taps from a zero page.
 // Measured (MI355X, random data): 460-590 TFLOP/s on the batch-32 encoder/prefill shapes, 637 at 8192^3,
 // against 340-380 / 456 for the fp32-activation kernel of k_gemm.hip.
+#include <stdlib.h>
+
 #include "dev.h"
 #include "kernels.h"
 
@@ -193,6 +195,151 @@ __global__ __launch_bounds__(256) void gemm16_kernel(ALoader A, const uint16_t* 
   }
 }
 
+// ---- small-M, K-heavy problems (one 30 s clip: M ~ 400, N ~ 1000, K 2048-7680) -------------------------------------
+// A 32x64 tile grid yields fewer workgroups than CUs there and every workgroup walks all of K alone (48-120 barrier-
+// separated steps).  Here the tile is 32 x BN and the workgroup's 4 waves split K instead: a K step stages
+// (32 + BN) x BKT bf16 (BKT = 256: 32 KiB per stage, two stages), wave w multiplies the k range [w*BKT/4, (w+1)*BKT/4)
+// of it, and the four partial 32 x BN accumulators are summed through LDS once at the end -- 4x fewer steps and BN = 32
+// doubles the workgroup count.  The epilogue then has 4 consecutive columns per thread: 16-B (fp32) / 8-B (bf16) stores.
+// LDS rows are BKT*2 = 512 / 256 B, so the 16 rows of a ds_read_b128 group share their bank offset; chunk c of row r is
+// kept at position (c & ~15) | ((c ^ r) & 15).
+__device__ __forceinline__ int kswz(int c, int row) { return (c & ~15) | ((c ^ row) & 15); }
+
+template <int BN, int BKT, class ALoader>
+__global__ __launch_bounds__(256) void gemm16k_kernel(ALoader A, const uint16_t* __restrict__ Wt, int M, int N, int K,
+                                                      GemmEpilogue ep) {
+  constexpr int BM = 32;
+  constexpr int CPR = BKT / 8;             // 16-B chunks per tile row (32 / 16)
+  constexpr int RPI = 64 / CPR;            // tile rows per wave instruction (2 / 4)
+  constexpr int A_LOADS = BM / (4 * RPI);  // glds instructions per wave per K step
+  constexpr int W_LOADS = BN / (4 * RPI);
+  constexpr int KS = BKT / 4 / 32;         // MFMA k-steps per wave per K step (2 / 1)
+  constexpr int MI = BM / 16, NI = BN / 16;
+  static_assert(A_LOADS >= 1 && W_LOADS >= 1 && KS >= 1, "tile shape");
+  static_assert(2 * BM * BKT * 2 >= 4 * BM * BN * 4, "reduction buffer must fit in the A stages");
+  __shared__ __attribute__((aligned(16))) uint16_t As[2][BM * BKT];
+  __shared__ __attribute__((aligned(16))) uint16_t Ws[2][BN * BKT];
+
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {  // bijective XCD remap: consecutive tile ids (sharing the W panel) stay on one XCD / L2
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  const int l_row = lane / CPR, l_pos = lane % CPR;
+  int a_s0[A_LOADS], a_s1[A_LOADS], a_s2[A_LOADS], a_chunk[A_LOADS];
+  const uint16_t* w_src[W_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int row = (i * 4 + wave) * RPI + l_row;
+    a_chunk[i] = kswz(l_pos, row);  // LDS position l_pos of this row holds global chunk kswz(l_pos, row) (an involution)
+    A.init_row(m0 + row, M, a_s0[i], a_s1[i], a_s2[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < W_LOADS; ++i) {
+    const int row = (i * 4 + wave) * RPI + l_row;
+    const int n = n0 + row;
+    w_src[i] = Wt + (size_t)(n < N ? n : N - 1) * K + kswz(l_pos, row) * 8;
+  }
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frag_row = lane & 15, frag_kc = lane >> 4;
+  const int KT = K / BKT;
+  auto issue_tile = [&](int kt, int buf) {
+    const int k0 = kt * BKT;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const uint16_t* ap = A.row_ptr(a_s0[i], a_s1[i], a_s2[i], k0) + a_chunk[i] * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)ap, (lptr_t)(&As[buf][(i * 4 + wave) * RPI * BKT]), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < W_LOADS; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + k0), (lptr_t)(&Ws[buf][(i * 4 + wave) * RPI * BKT]), 16, 0, 0);
+  };
+  issue_tile(0, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    __syncthreads();  // lands tile kt (vmcnt(0) rides on the barrier) and retires every wave's reads of tile kt-1
+    if (kt + 1 < KT) issue_tile(kt + 1, buf ^ 1);
+    const uint16_t* as = As[buf];
+    const uint16_t* ws = Ws[buf];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = wave * (CPR / 4) + ks * 4 + frag_kc;  // this wave's quarter of the K step
+      bf16x8_t bfrag[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = j * 16 + frag_row;
+        bfrag[j] = *reinterpret_cast<const bf16x8_t*>(&ws[row * BKT + kswz(c, row) * 8]);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = i * 16 + frag_row;
+        const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(&as[row * BKT + kswz(c, row) * 8]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // ---- sum the four K quarters through LDS: red[wave][row][col] ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(&As[0][0]);
+  {
+    const int col_in = lane & 15, row_in = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * BM + i * 16 + row_in + r) * BN + j * 16 + col_in] = acc[i][j][r];
+  }
+  __syncthreads();
+  constexpr int TPR = BN / 4;  // threads per output row (4 columns each)
+  for (int e = tid; e < BM * TPR; e += 256) {
+    const int row = e / TPR, c4 = (e % TPR) * 4;
+    const int m = m0 + row, n = n0 + c4;
+    if (m >= M || n >= N) continue;
+    const int orow = ep.rowmap ? ep.rowmap[m] : m;
+    if (orow < 0) continue;
+    float4 v = *reinterpret_cast<const float4*>(&red[row * BN + c4]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 p = *reinterpret_cast<const float4*>(&red[(w * BM + row) * BN + c4]);
+      v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (ep.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(ep.bias + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (ep.addend) {
+      const float4 b = *reinterpret_cast<const float4*>(ep.addend + (size_t)(m % ep.addend_period) * ep.ldo + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (ep.act == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+    if (ep.resid) {
+      const float4 b = *reinterpret_cast<const float4*>(ep.resid + (size_t)orow * ep.ldo + n);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (ep.out16) {
+      uint2 pk;
+      pk.x = pack_bf16x2(v.x, v.y);
+      pk.y = pack_bf16x2(v.z, v.w);
+      *reinterpret_cast<uint2*>(ep.out16 + (size_t)orow * ep.ldo + n) = pk;
+    } else {
+      *reinterpret_cast<float4*>(ep.out + (size_t)orow * ep.ldo + n) = v;
+    }
+  }
+}
+
 template <int BM, int BN, int BK, bool GLU, class ALoader>
 void launch16(const ALoader& A, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -240,6 +387,14 @@ const char* launch_gemm16(const uint16_t* X, int lda, const uint16_t* W, int M, 
   if (K % 32 != 0 || lda % 8 != 0) return "gemm16: K must be a multiple of 32 and lda of 8";
   if (glu && N % 32 != 0) return "gemm16: GLU needs N % 32 == 0";
   DenseA16 A{X, lda};
+  // few tiles and a long K: 32x32 tiles whose 4 waves split K (A/B knob: Q3A_GEMM16_KSPLIT=0 disables)
+  static const bool ksplit_on = [] { const char* e = getenv("Q3A_GEMM16_KSPLIT"); return !e || atoi(e) != 0; }();
+  if (ksplit_on && !glu && tiles_of(M, N, 32, 64) < 384 && K >= 512 && K % 128 == 0 && N % 4 == 0 && ep.ldo % 4 == 0) {
+    const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
+    if (K % 256 == 0) hipLaunchKernelGGL((gemm16k_kernel<32, 256, DenseA16>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
+    else hipLaunchKernelGGL((gemm16k_kernel<32, 128, DenseA16>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
+    return nullptr;
+  }
   if (K % 64 == 0) {
     if (glu) launch_sized16<64, true>(A, W, M, N, K, ep, s); else launch_sized16<64, false>(A, W, M, N, K, ep, s);
   } else {

@@ -54,6 +54,24 @@ __global__ __launch_bounds__(256) void k_gemv(const float* __restrict__ x, const
   }
 }
 
+// reads `bytes` once, 16 B per lane, 16-KiB chunk c from workgroup (c + 1) % gridDim.x
+template <bool NT>
+__global__ __launch_bounds__(256) void k_prefetch(const uint16_t* __restrict__ w, size_t bytes, int* sink) {
+  const size_t chunk = ((size_t)blockIdx.x + gridDim.x - 1) % gridDim.x;
+  const char* base = reinterpret_cast<const char*>(w) + chunk * 16384;
+  unsigned acc = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const size_t off = chunk * 16384 + (size_t)j * 4096 + threadIdx.x * 16;
+    if (off < bytes) {
+      const u32x4_t* p = reinterpret_cast<const u32x4_t*>(base + j * 4096 + threadIdx.x * 16);
+      const u32x4_t v = NT ? __builtin_nontemporal_load(p) : *p;
+      acc ^= v.x ^ v.w;
+    }
+  }
+  if (acc == 0x7fc12345u) *sink = 1;
+}
+
 template <class F>
 static int time_graph(const char* name, int n, hipStream_t s, F&& enqueue, double bytes_per_launch = 0) {
   hipGraph_t g;
@@ -216,6 +234,35 @@ int main() {
           const char* e = q3a::launch_decode_attn(a, 1, false, s);
           if (e) printf("launch_decode_attn: %s\n", e);
         })) return 1;
+  }
+  // does a weight matrix that another kernel has just pulled through the Infinity Cache stream faster?  The prefetch
+  // reads chunk c from workgroup c+1 (another XCD than the GEMV workgroup that consumes it: L2 misses, MALL hits)
+  {
+    const int N = 6144, K = 1024;
+    const size_t stride = (size_t)N * K;
+    const int slots = (int)(WB / 2 / stride);
+    float* rmsw; float* big; int* sink;
+    CHK(hipMalloc(&rmsw, 8192 * 4)); CHK(hipMalloc(&big, 8192 * 4)); CHK(hipMalloc(&sink, 4));
+    CHK(hipMemset(rmsw, 0, 8192 * 4)); CHK(hipMemset(big, 0, 8192 * 4));
+    auto gemv = [&](int i, const uint16_t* w) {
+      q3a::GemvArgs a{};
+      a.x = (i & 1) ? big : x; a.ldx = K; a.rms_w = rmsw; a.eps = 1e-6f; a.W = w; a.N = N; a.K = K; a.mode = 2;
+      a.out = (i & 1) ? x : big; a.ldo = N / 2;
+      const char* e = q3a::launch_gemv(a, 1, s);
+      if (e) printf("launch_gemv: %s\n", e);
+    };
+    for (int nt = 0; nt < 2; ++nt) {
+      auto pf = [&](const uint16_t* w) {
+        if (nt) hipLaunchKernelGGL((k_prefetch<true>), dim3(768), dim3(256), 0, s, w, stride * 2, sink);
+        else hipLaunchKernelGGL((k_prefetch<false>), dim3(768), dim3(256), 0, s, w, stride * 2, sink);
+      };
+      if (time_graph(nt ? "prefetch kernel alone 12.6 MB (nt loads)" : "prefetch kernel alone 12.6 MB (plain loads)", n, s,
+                     [&](int i) { pf(W + (size_t)(i % slots) * stride); }, stride * 2.0)) return 1;
+      if (time_graph(nt ? "prefetch(nt) + gateup GEMV on the same matrix" : "prefetch(plain) + gateup GEMV on the same matrix", n / 2, s,
+                     [&](int i) { const uint16_t* w = W + (size_t)(i % slots) * stride; pf(w); gemv(i, w); }, stride * 2.0)) return 1;
+    }
+    if (time_graph("gateup GEMV twice on the same matrix (2nd: L2/MALL warm)", n / 2, s,
+                   [&](int i) { const uint16_t* w = W + (size_t)(i % slots) * stride; gemv(i, w); gemv(i + 1, w); }, stride * 4.0)) return 1;
   }
   // eager (no graph) chain for comparison
   {
