@@ -132,7 +132,7 @@ def main():
     if rank == 0:
         audio_seconds = world * B * args.seconds * args.steps
         if stream_prof is not None:
-            kname = "gemv1_kernel<2,2,2> (decode qkv + gate/up GEMV: RMSNorm + weight streaming [+SwiGLU])"
+            kname = "gemv1_kernel<2,2,true,false> (decode qkv + gate/up GEMV: RMSNorm + weight streaming [+SwiGLU])"
             bytes_per_launch, avg_us, n_launch = stream_prof["bytes_per_launch"], stream_prof["avg_us"], 56
         else:
             g = prof["gemm"]
@@ -144,7 +144,9 @@ def main():
         pmc_file = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")  # rocprofv3 --pmc passes, see DESIGN.md section 6
         if stream_prof is not None and args.preset == "0.6b" and os.path.exists(pmc_file):
             try:
-                traffic = json.load(open(pmc_file))["gemv1_kernel<2, 2, 2>"]["hbm_bytes_per_launch"]
+                pmc = json.load(open(pmc_file))
+                key = [k for k in pmc if k.startswith("gemv1_kernel<2, 2, true")][0]
+                traffic = pmc[key]["hbm_bytes_per_launch"]
             except Exception:  # noqa: BLE001
                 traffic = None
         out = {

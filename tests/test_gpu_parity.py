@@ -40,6 +40,20 @@ def test_gemm_against_device_reference(shape, split):
     assert err <= (2e-5 if split else 4e-3) * ref, (err, ref)
 
 
+@pytest.mark.parametrize("shape", [
+    (128, 128, 64), (130, 200, 96),                      # 32x64 tiles, ragged M/N, BK = 32 path (K % 64 != 0)
+    (70, 96, 256), (33, 36, 512), (390, 896, 3584),      # 32x32 tiles, 4 waves split K (BKT = 256)
+    (390, 1024, 896),                                    # same with BKT = 128 (K % 256 != 0)
+    (405, 4096, 1024), (1000, 480, 4320), (3000, 3584, 896),  # 64x64 and 128x128 tiles
+])
+def test_gemm16_against_device_reference(shape):
+    """bf16-activation LDS-DMA GEMM (default mode) vs the fp64-accumulating device reference on the same bf16 inputs:
+    products are exact, only the fp32 summation order differs."""
+    from qwen3_asr_rs_amd.engine import selftest_gemm16
+    r = selftest_gemm16(*shape)
+    assert r["err"] <= 2e-5 * max(r["ref_max"], 1.0), r
+
+
 def test_mel_reference_clips_and_hf_golden(tiny_dir):
     """Weight-free stage: real parity on the reference's own clips, also against the HF fixture."""
     eng = HipEngine(tiny_dir, 0)
