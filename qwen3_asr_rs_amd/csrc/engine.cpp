@@ -520,6 +520,14 @@ struct q3a_engine {
       g.part_val = part_val.as<float>(); g.part_idx = part_idx.as<int>(); g.part_stride = part_stride;
       n_part = gemv_blocks(g);
       timed(Q3A_KC_GEMV_LM_HEAD, wbytes, [&] { KCHK(launch_gemv(g, S, stream)); });
+    } else if (!precise()) {
+      // default mode: bf16 normed rows, then the LDS-DMA GEMM at M = S (32-row tiles) -- the vocabulary matrix is
+      // streamed once through double-buffered LDS; the skinny kernel re-reads x per 16 vocabulary rows (3x slower here)
+      timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(L.final_norm), s_ln.as<float>(), S, H, d.rms_eps, stream, s_ln.as<uint16_t>())); });
+      GemmEpilogue ep; ep.out = logits.as<float>(); ep.ldo = V;
+      timed(Q3A_KC_GEMM, wbytes, [&] { KCHK(launch_gemm16(s_ln.as<uint16_t>(), H, wh(L.lm_head), S, V, H, ep, false, stream)); });
+      n_part = 128;
+      timed(Q3A_KC_ARGMAX, 0, [&] { KCHK(launch_argmax_partials(logits.as<float>(), V, S, part_val.as<float>(), part_idx.as<int>(), part_stride, n_part, stream)); });
     } else {
       timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(L.final_norm), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
       timed(Q3A_KC_GEMM, wbytes, [&] { batched_proj(s_ln.as<float>(), H, wh(L.lm_head), V, H, nullptr, 0, logits.as<float>(), V, nullptr); });
@@ -629,6 +637,11 @@ struct q3a_engine {
         g.x = x_dec.as<float>(); g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
         g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = s_qkv.as<float>(); g.ldo = QKV;
         timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, stream)); });
+      } else if (S <= 32) {
+        SkinnyArgs q{};
+        q.x = x_dec.as<float>(); q.ldx = H; q.S = S; q.rms_w = wf(l.in_ln); q.eps = d.rms_eps; q.W = wh(l.qkv_w); q.N = QKV; q.K = H;
+        q.bias = qkv_bias ? wf(l.qkv_b) : nullptr; q.mode = 0; q.out = s_qkv.as<float>(); q.ldo = QKV;
+        timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { KCHK(launch_skinny(q, precise(), stream)); });
       } else {
         timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(l.in_ln), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
         timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { batched_proj(s_ln.as<float>(), H, wh(l.qkv_w), QKV, H, qkv_bias ? wf(l.qkv_b) : nullptr, 0, s_qkv.as<float>(), QKV, nullptr); });
@@ -655,6 +668,23 @@ struct q3a_engine {
         dn.x = s_act.as<float>(); dn.ldx = I; dn.W = wh(l.down_w); dn.N = H; dn.K = I; dn.bias = mlp_bias ? wf(l.down_b) : nullptr;
         dn.mode = 1; dn.out = x_dec.as<float>(); dn.ldo = H; dn.resid = x_dec.as<float>();
         timed(Q3A_KC_GEMV_DOWN, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, stream)); });
+      } else if (S <= 32) {
+        // skinny MFMA GEMMs: the norms are fused (no norm launches), and in the default mode the two K-heavy
+        // projections read bf16 activations written by their producers (attention merge, SwiGLU epilogue)
+        const bool b16 = !precise();
+        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream, b16 ? s_ctx.as<uint16_t>() : nullptr)); });
+        SkinnyArgs o{};
+        o.x = s_ctx.as<float>(); o.x16 = b16 ? s_ctx.as<uint16_t>() : nullptr; o.ldx = QD; o.S = S; o.W = wh(l.o_w); o.N = H; o.K = QD;
+        o.bias = o_bias ? wf(l.o_b) : nullptr; o.mode = 1; o.out = x_dec.as<float>(); o.ldo = H; o.resid = x_dec.as<float>();
+        timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { KCHK(launch_skinny(o, precise(), stream)); });
+        SkinnyArgs u{};
+        u.x = x_dec.as<float>(); u.ldx = H; u.S = S; u.rms_w = wf(l.post_ln); u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
+        u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act.as<float>(); u.out16 = b16 ? s_act.as<uint16_t>() : nullptr; u.ldo = I;
+        timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_skinny(u, precise(), stream)); });
+        SkinnyArgs dn{};
+        dn.x = s_act.as<float>(); dn.x16 = b16 ? s_act.as<uint16_t>() : nullptr; dn.ldx = I; dn.S = S; dn.W = wh(l.down_w); dn.N = H; dn.K = I;
+        dn.bias = mlp_bias ? wf(l.down_b) : nullptr; dn.mode = 1; dn.out = x_dec.as<float>(); dn.ldo = H; dn.resid = x_dec.as<float>();
+        timed(Q3A_KC_GEMM, 2.0 * H * I, [&] { KCHK(launch_skinny(dn, precise(), stream)); });
       } else {
         timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream)); });
         timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { batched_proj(s_ctx.as<float>(), QD, wh(l.o_w), H, QD, o_bias ? wf(l.o_b) : nullptr, 1, x_dec.as<float>(), H, x_dec.as<float>()); });

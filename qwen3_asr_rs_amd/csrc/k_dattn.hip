@@ -228,7 +228,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
 
 // merge of the split partials into [S][n_q*128] (only the GEMM decode path needs it as a separate launch)
 __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
-                                                           const float* __restrict__ po, int nsplit, float* __restrict__ out) {
+                                                           const float* __restrict__ po, int nsplit, float* __restrict__ out,
+                                                           uint16_t* __restrict__ out16) {
   const size_t sh = blockIdx.x;  // (sequence, head) flattened
   const int d = threadIdx.x;
   float M = -INFINITY;
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restri
     L += pl[sh * nsplit + sp] * f;
     o += po[(sh * nsplit + sp) * 128 + d] * f;
   }
-  out[sh * 128 + d] = o / L;
+  if (out16) out16[sh * 128 + d] = (uint16_t)f32_to_bf16_bits(o / L);  // feeds the bf16-x skinny GEMM (o_proj)
+  else out[sh * 128 + d] = o / L;
 }
 
 }  // namespace
@@ -265,9 +267,9 @@ const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipS
 }
 
 const char* launch_attn_combine(const float* pm, const float* pl, const float* po, int nsplit, int S, int n_q, float* out,
-                                hipStream_t s) {
+                                hipStream_t s, uint16_t* out16) {
   if (S <= 0) return nullptr;
-  hipLaunchKernelGGL(attn_combine_kernel, dim3(S * n_q), dim3(128), 0, s, pm, pl, po, nsplit, out);
+  hipLaunchKernelGGL(attn_combine_kernel, dim3(S * n_q), dim3(128), 0, s, pm, pl, po, nsplit, out, out16);
   return nullptr;
 }
 

@@ -351,7 +351,8 @@ inline long tiles_of(int M, int N, int bm, int bn) { return (long)((M + bm - 1) 
 // tile by workgroup count: enough 128x128 tiles to fill 256 CUs 1.5x over, else 64x64, else 32x64
 template <int BK, bool GLU, class ALoader>
 void launch_sized16(const ALoader& A, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s) {
-  if (tiles_of(M, N, 128, 128) >= 384) launch16<128, 128, BK, GLU>(A, W, M, N, K, ep, s);
+  if (M <= 32) launch16<32, 64, BK, GLU>(A, W, M, N, K, ep, s);  // batched decode lm_head: pure weight streaming
+  else if (tiles_of(M, N, 128, 128) >= 384) launch16<128, 128, BK, GLU>(A, W, M, N, K, ep, s);
   else if (tiles_of(M, N, 64, 64) >= 384) launch16<64, 64, BK, GLU>(A, W, M, N, K, ep, s);
   else launch16<32, 64, BK, GLU>(A, W, M, N, K, ep, s);
 }

@@ -375,9 +375,8 @@ __global__ __launch_bounds__(256) void gemvn_kernel(GemvArgs a) {
   for (int it = 0; it < PF; ++it) {
     const int k = lane * 8 + it * 512;
 #pragma unroll
-    for (int i = 0; i < PR; ++i)
-      wq[it][i] = (prow[i] >= 0 && k < K) ? ld_stream16(a.W + (size_t)prow[i] * K + k)
-                                          : make_uint4(0u, 0u, 0u, 0u);
+    for (int i = 0; i < PR; ++i)  // unconditional (clamped) loads: no exec-masked blocks, no waits between requests
+      wq[it][i] = ld_stream16(a.W + (size_t)(prow[i] >= 0 ? prow[i] : a.N - 1) * K + (k < K ? k : 0));
   }
   __shared__ AttnTables f_s;
   if (a.attn_po) attn_scales(a, NB, f_s);
@@ -433,7 +432,7 @@ __global__ __launch_bounds__(256) void gemvn_kernel(GemvArgs a) {
     uint4 w[PR];
 #pragma unroll
     for (int i = 0; i < PR; ++i)
-      w[i] = prow[i] >= 0 ? ld_stream16(a.W + (size_t)prow[i] * K + k) : make_uint4(0u, 0u, 0u, 0u);
+      w[i] = ld_stream16(a.W + (size_t)(prow[i] >= 0 ? prow[i] : a.N - 1) * K + k);
     fma_all(w, k);
   }
 #pragma unroll

@@ -1,7 +1,8 @@
 // Skinny MFMA GEMM for the batched decode step on gfx950: out[s][n] = sum_k x[s][k] * W[n][k] with
 // 4 < S <= 32 sequences.  Replaces Linear::forward (src/layers.rs:74-80) for one token of each of S
-// independent utterances; every weight byte is still streamed from HBM exactly once per step, now amortised
-// over up to 32 sequences.
+// independent utterances -- with the RMSNorm in front of it (layers.rs:48-54) and the SiLU(gate)*up behind it
+// (layers.rs:396-400) fused where they apply; every weight byte is still streamed from HBM exactly once per step,
+// now amortised over up to 32 sequences.
 //
 // The step is latency-bound (a CU sustains only ~16 GB/s when it waits for one round trip per 8 KB), so the
 // kernel is shaped to put a workgroup's whole weight slab in flight at once: one workgroup = 16 weight rows
@@ -9,10 +10,15 @@
 // all loads of four 32-wide k-steps before its first MFMA.  Per k-step
 //   A = W fragment : lane (row l&15, k-chunk l>>4) loads its 16 B from the row-major bf16 matrix
 //                    (4 lanes cover 64 contiguous bytes of a row)
-//   B = x fragment : lane (sequence l&15 [+16], same k-chunk) loads 8 fp32 activations (L2-resident) and rounds
-//                    them to bf16 (default) or splits them into bf16 hi + lo (precise mode: two MFMAs)
+//   B = x fragment : lane (sequence l&15 [+16], same k-chunk) holds 8 activations as bf16.  Three sources (XMODE):
+//                    0  fp32 x, rounded to bf16 (default) or split into bf16 hi + lo (precise mode: two MFMAs);
+//                    1  fp32 x with the RMSNorm fused: x * w_norm enters the MFMA, sum(x^2) is accumulated on the
+//                       side and 1/rms scales the finished dot product (a scalar per sequence) -- no norm launch;
+//                    2  bf16 x written by the producing kernel (attention merge, SwiGLU epilogue): one 16-B load,
+//                       no conversion, half the L2 bytes (x is re-read by every workgroup: at N = 1024 it outweighs
+//                       the workgroup's own weight slab 4:1 in fp32)
 //   v_mfma_f32_16x16x32_bf16 -> D[row][sequence], sequences 0-15 and 16-31 share the A fragment.
-// The eight K-slices are summed through LDS in a fixed order (deterministic), then bias / residual /
+// The eight K-slices are summed through LDS in a fixed order (deterministic), then 1/rms, bias / residual /
 // SiLU(gate)*up are applied.
 #include "dev.h"
 #include "kernels.h"
@@ -35,11 +41,15 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, bf16x8_
   hi = *reinterpret_cast<const bf16x8_t*>(&h);
   lo = *reinterpret_cast<const bf16x8_t*>(&l);
 }
+__device__ __forceinline__ float4 mul4(const float4& a, const float4& b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float sq4(const float4& a) { return a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
 
 // TILES = 16-row weight tiles per workgroup (1, or 2 = gate + up); SH = 16-sequence halves (1: S <= 16, 2: S <= 32)
-template <bool SPLIT, int TILES, int SH>
+template <bool SPLIT, int TILES, int SH, int XMODE>
 __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
+  static_assert(!(SPLIT && XMODE == 2), "the precise mode keeps fp32 activations");
   __shared__ float part[SK_WAVES][TILES][SH][16][17];  // [k-slice][tile][seq half][row][sequence] (+1 pad)
+  __shared__ float ssp[SK_WAVES][SH][16];              // XMODE 1: sum(x^2) of each sequence over the wave's K slice
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kc = lane >> 4;  // row / sequence inside the fragment, k-chunk (8 elements)
   const int n0 = blockIdx.x * 16 * TILES;
@@ -54,12 +64,19 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     wrow[t] = a.W + (size_t)(row < a.N ? row : a.N - 1) * K + kc * 8;
   }
   const float* xrow[SH];
+  const uint16_t* xrow16[SH];
 #pragma unroll
   for (int h = 0; h < SH; ++h) {
     const int s = h * 16 + l15;
-    xrow[h] = a.x + (size_t)(s < a.S ? s : a.S - 1) * a.ldx + kc * 8;
+    const size_t off = (size_t)(s < a.S ? s : a.S - 1) * a.ldx + kc * 8;
+    xrow[h] = a.x + off;
+    xrow16[h] = a.x16 + off;
   }
+  const float* nrow = a.rms_w + kc * 8;
   f32x4_t acc[TILES][SH];
+  float ss[SH];
+#pragma unroll
+  for (int h = 0; h < SH; ++h) ss[h] = 0.f;
 #pragma unroll
   for (int t = 0; t < TILES; ++t)
 #pragma unroll
@@ -68,29 +85,49 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   constexpr int UNR = 4;
   for (int kb = ks0; kb < ks1; kb += UNR) {
     uint4 wv[UNR][TILES];
-    float4 x0[UNR][SH], x1[UNR][SH];
+    float4 x0[UNR][SH], x1[UNR][SH], w0[UNR], w1[UNR];
+    uint4 xq[UNR][SH];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const bool live = kb + u < ks1;
       const int ks = live ? kb + u : ks1 - 1;  // clamp the address, zero the weight of the tail
 #pragma unroll
       for (int t = 0; t < TILES; ++t) {
-        wv[u][t] = *reinterpret_cast<const uint4*>(wrow[t] + ks * 32);
+        wv[u][t] = ld_stream16(wrow[t] + ks * 32);
         if (!live) wv[u][t] = make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
       for (int h = 0; h < SH; ++h) {
-        x0[u][h] = *reinterpret_cast<const float4*>(xrow[h] + ks * 32);
-        x1[u][h] = *reinterpret_cast<const float4*>(xrow[h] + ks * 32 + 4);
+        if (XMODE == 2) {
+          xq[u][h] = *reinterpret_cast<const uint4*>(xrow16[h] + ks * 32);
+        } else {
+          x0[u][h] = *reinterpret_cast<const float4*>(xrow[h] + ks * 32);
+          x1[u][h] = *reinterpret_cast<const float4*>(xrow[h] + ks * 32 + 4);
+        }
+      }
+      if (XMODE == 1) {
+        w0[u] = *reinterpret_cast<const float4*>(nrow + ks * 32);
+        w1[u] = *reinterpret_cast<const float4*>(nrow + ks * 32 + 4);
       }
     }
 #pragma unroll
-    for (int u = 0; u < UNR; ++u)
+    for (int u = 0; u < UNR; ++u) {
+      const bool live = kb + u < ks1;
 #pragma unroll
       for (int h = 0; h < SH; ++h) {
         bf16x8_t hi, lo;
-        if (SPLIT) split8(x0[u][h], x1[u][h], hi, lo);
-        else hi = pack8(x0[u][h], x1[u][h]);
+        if (XMODE == 2) {
+          hi = *reinterpret_cast<const bf16x8_t*>(&xq[u][h]);
+        } else {
+          float4 p0 = x0[u][h], p1 = x1[u][h];
+          if (XMODE == 1) {
+            if (live) ss[h] += sq4(p0) + sq4(p1);
+            p0 = mul4(p0, w0[u]);
+            p1 = mul4(p1, w1[u]);
+          }
+          if (SPLIT) split8(p0, p1, hi, lo);
+          else hi = pack8(p0, p1);
+        }
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
           const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&wv[u][t]);
@@ -98,6 +135,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
           if (SPLIT) acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, lo, acc[t][h], 0, 0, 0);
         }
       }
+    }
   }
   // D[row i][sequence j] of v_mfma_f32_16x16x32: j = lane&15, i = (lane>>4)*4 + r
 #pragma unroll
@@ -106,17 +144,34 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     for (int h = 0; h < SH; ++h)
 #pragma unroll
       for (int r = 0; r < 4; ++r) part[wave][t][h][kc * 4 + r][l15] = acc[t][h][r];
+  if (XMODE == 1) {
+#pragma unroll
+    for (int h = 0; h < SH; ++h) {
+      float v = ss[h];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);  // the four k-chunk lanes of this sequence
+      if (kc == 0) ssp[wave][h][l15] = v;
+    }
+  }
   __syncthreads();
   // ---- fixed-order reduction of the K-slices + epilogue: thread -> (row i, sequence s) ----
   const int i = tid >> 5, s = tid & 31;  // 16 rows x 32 sequences = 512 threads
   if (s >= a.S || (SH == 1 && s >= 16)) return;
-  const int sh = s >> 4, sj = s & 15;
+  const int sh = SH == 1 ? 0 : s >> 4, sj = s & 15;
   float v[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
     v[t] = 0.f;
 #pragma unroll
-    for (int w = 0; w < SK_WAVES; ++w) v[t] += part[w][t][SH == 1 ? 0 : sh][i][sj];
+    for (int w = 0; w < SK_WAVES; ++w) v[t] += part[w][t][sh][i][sj];
+  }
+  if (XMODE == 1) {
+    float q = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) q += ssp[w][sh][sj];
+    const float rstd = 1.0f / sqrtf(q / (float)K + a.eps);
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) v[t] *= rstd;
   }
   if (TILES == 1) {
     const int n = n0 + i;
@@ -129,21 +184,23 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     if (n0 + 16 + i >= a.N) return;
     float g = v[0], u = v[TILES - 1];
     if (a.bias) { g += a.bias[n0 + i]; u += a.bias[n0 + 16 + i]; }
-    a.out[(size_t)s * a.ldo + (n0 >> 1) + i] = silu_f(g) * u;
+    const float y = silu_f(g) * u;
+    if (a.out16) a.out16[(size_t)s * a.ldo + (n0 >> 1) + i] = (uint16_t)f32_to_bf16_bits(y);
+    else a.out[(size_t)s * a.ldo + (n0 >> 1) + i] = y;
   }
 }
 
-template <bool SPLIT>
+template <bool SPLIT, int XMODE>
 void launch_s(const SkinnyArgs& a, hipStream_t s) {
   const dim3 block(SK_WAVES * 64);
   if (a.mode == 2) {
     const dim3 grid((a.N + 31) / 32);
-    if (a.S <= 16) hipLaunchKernelGGL((skinny_kernel<SPLIT, 2, 1>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((skinny_kernel<SPLIT, 2, 2>), grid, block, 0, s, a);
+    if (a.S <= 16) hipLaunchKernelGGL((skinny_kernel<SPLIT, 2, 1, XMODE>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((skinny_kernel<SPLIT, 2, 2, XMODE>), grid, block, 0, s, a);
   } else {
     const dim3 grid((a.N + 15) / 16);
-    if (a.S <= 16) hipLaunchKernelGGL((skinny_kernel<SPLIT, 1, 1>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((skinny_kernel<SPLIT, 1, 2>), grid, block, 0, s, a);
+    if (a.S <= 16) hipLaunchKernelGGL((skinny_kernel<SPLIT, 1, 1, XMODE>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((skinny_kernel<SPLIT, 1, 2, XMODE>), grid, block, 0, s, a);
   }
 }
 
@@ -152,10 +209,13 @@ void launch_s(const SkinnyArgs& a, hipStream_t s) {
 const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s) {
   if (a.S <= 0) return nullptr;
   if (a.S > 32) return "skinny gemm: at most 32 sequences";
-  if (a.K % 32 != 0 || a.ldx % 4 != 0) return "skinny gemm: K must be a multiple of 32, ldx of 4";
+  if (a.K % 32 != 0 || a.ldx % 8 != 0) return "skinny gemm: K must be a multiple of 32, ldx of 8";
   if (a.mode == 2 && a.N % 32 != 0) return "skinny gemm: GLU needs N % 32 == 0";
-  if (split) launch_s<true>(a, s);
-  else launch_s<false>(a, s);
+  if (a.out16 && a.mode != 2) return "skinny gemm: bf16 output only in GLU mode";
+  if (a.x16 && (split || a.rms_w)) return "skinny gemm: bf16 x excludes the precise mode and the fused RMSNorm";
+  if (a.x16) launch_s<false, 2>(a, s);
+  else if (a.rms_w) { if (split) launch_s<true, 1>(a, s); else launch_s<false, 1>(a, s); }
+  else { if (split) launch_s<true, 0>(a, s); else launch_s<false, 0>(a, s); }
   return nullptr;
 }
 

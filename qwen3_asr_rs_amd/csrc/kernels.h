@@ -132,11 +132,14 @@ int gemv_rows_per_wave(const GemvArgs& a);
 
 // Skinny MFMA GEMM (k_skinny.hip): 4 < S <= 32 sequences, weights streamed once.
 struct SkinnyArgs {
-  const float* x; int ldx; int S;   // [S][K] fp32
+  const float* x; int ldx; int S;   // [S][K] fp32 ...
+  const uint16_t* x16;              // ... or, when non-null, the same as bf16 (default mode: written by the producer)
+  const float* rms_w; float eps;    // non-null (fp32 x only): RMSNorm fused -- x*w enters the MFMA, rstd scales the result
   const uint16_t* W; int N; int K;  // bf16 [N][K]
   const float* bias;                // [N] or null
   int mode;                         // 0: store, 1: out = resid + y, 2: GLU ([16 gate|16 up] row blocks, out has N/2 columns)
   float* out; int ldo;
+  uint16_t* out16;                  // mode 2 only: when non-null the result is written here as bf16 instead of out
   const float* resid;
 };
 const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s);
@@ -158,7 +161,7 @@ inline int dattn_keys_per_split(bool kv_f32) { return kv_f32 ? DATTN_KEYS_PER_SP
 const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
 // out[S][n_q*128] = merged partials (needed as its own launch only on the GEMM decode path)
 const char* launch_attn_combine(const float* pm, const float* pl, const float* po, int nsplit, int S, int n_q, float* out,
-                                hipStream_t s);
+                                hipStream_t s, uint16_t* out16 = nullptr);  // out16 != null: bf16 there instead of out
 
 struct FinalizeArgs {
   const float* part_val;   // [S][part_stride] block-partial maxima ...
