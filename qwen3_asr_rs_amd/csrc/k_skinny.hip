@@ -27,6 +27,9 @@ namespace q3a {
 namespace {
 
 constexpr int SK_WAVES = 8;
+#ifndef Q3A_SK_EXP
+#define Q3A_SK_EXP 0  // timing experiments of tools/launch_floor.hip only
+#endif
 
 __device__ __forceinline__ bf16x8_t pack8(const float4& a, const float4& b) {
   uint4 p;
@@ -45,7 +48,9 @@ __device__ __forceinline__ float4 mul4(const float4& a, const float4& b) { retur
 __device__ __forceinline__ float sq4(const float4& a) { return a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
 
 // TILES = 16-row weight tiles per workgroup (1, or 2 = gate + up); SH = 16-sequence halves (1: S <= 16, 2: S <= 32)
-template <bool SPLIT, int TILES, int SH, int XMODE>
+// UNR = k-steps whose loads a wave issues before its first MFMA: the launcher picks it to cover the wave's whole K
+// slice (K/8: 4 steps at K = 1024, 12 at K = 3072), so a wave makes ONE memory round trip, not K/8/4 of them
+template <bool SPLIT, int TILES, int SH, int XMODE, int UNR>
 __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   static_assert(!(SPLIT && XMODE == 2), "the precise mode keeps fp32 activations");
   __shared__ float part[SK_WAVES][TILES][SH][16][17];  // [k-slice][tile][seq half][row][sequence] (+1 pad)
@@ -56,23 +61,28 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   const int K = a.K;
   const int steps = K / 32, per = (steps + SK_WAVES - 1) / SK_WAVES;
   const int ks0 = wave * per, ks1 = min(steps, ks0 + per);
+  // Measured (tools/launch_floor.hip, S = 32): these fragment loads touch 16 cache lines per wave instruction (16 rows
+  // x 64 B) and the L1 retires them at ~16 B/clk per CU -- at N = 1024 (64 workgroups) that, not HBM, is the bound:
+  // down-proj 12.2 us = 6.3 (W) + 7.2 (x) - overlap.  Pairing k-steps so that 4 lanes cover a whole 128-B line in two
+  // back-to-back loads did not help (+0.3..0.9 us); a fragment-ordered activation layout is the next step.
+  constexpr int kcw = 8;
   // out-of-range rows / sequences are clamped to valid memory: their products are discarded by the epilogue
   const uint16_t* wrow[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
     const int row = n0 + t * 16 + l15;
-    wrow[t] = a.W + (size_t)(row < a.N ? row : a.N - 1) * K + kc * 8;
+    wrow[t] = a.W + (size_t)(row < a.N ? row : a.N - 1) * K + kc * kcw;
   }
   const float* xrow[SH];
   const uint16_t* xrow16[SH];
 #pragma unroll
   for (int h = 0; h < SH; ++h) {
     const int s = h * 16 + l15;
-    const size_t off = (size_t)(s < a.S ? s : a.S - 1) * a.ldx + kc * 8;
+    const size_t off = (size_t)(s < a.S ? s : a.S - 1) * a.ldx + kc * kcw;
     xrow[h] = a.x + off;
     xrow16[h] = a.x16 + off;
   }
-  const float* nrow = a.rms_w + kc * 8;
+  const float* nrow = a.rms_w + kc * kcw;
   f32x4_t acc[TILES][SH];
   float ss[SH];
 #pragma unroll
@@ -82,7 +92,6 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int h = 0; h < SH; ++h) acc[t][h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  constexpr int UNR = 4;
   for (int kb = ks0; kb < ks1; kb += UNR) {
     uint4 wv[UNR][TILES];
     float4 x0[UNR][SH], x1[UNR][SH], w0[UNR], w1[UNR];
@@ -91,23 +100,32 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     for (int u = 0; u < UNR; ++u) {
       const bool live = kb + u < ks1;
       const int ks = live ? kb + u : ks1 - 1;  // clamp the address, zero the weight of the tail
+      const int ko = ks * 32;  // element offset of this step inside the row
 #pragma unroll
       for (int t = 0; t < TILES; ++t) {
-        wv[u][t] = ld_stream16(wrow[t] + ks * 32);
+#if (Q3A_SK_EXP & 2)
+        wv[u][t] = make_uint4(ks, lane, 0u, 0u);
+#else
+        wv[u][t] = ld_stream16(wrow[t] + ko);
+#endif
         if (!live) wv[u][t] = make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
       for (int h = 0; h < SH; ++h) {
         if (XMODE == 2) {
-          xq[u][h] = *reinterpret_cast<const uint4*>(xrow16[h] + ks * 32);
+#if (Q3A_SK_EXP & 1)
+          xq[u][h] = make_uint4(ks, lane, 0u, 0u);
+#else
+          xq[u][h] = *reinterpret_cast<const uint4*>(xrow16[h] + ko);
+#endif
         } else {
-          x0[u][h] = *reinterpret_cast<const float4*>(xrow[h] + ks * 32);
-          x1[u][h] = *reinterpret_cast<const float4*>(xrow[h] + ks * 32 + 4);
+          x0[u][h] = *reinterpret_cast<const float4*>(xrow[h] + ko);
+          x1[u][h] = *reinterpret_cast<const float4*>(xrow[h] + ko + 4);
         }
       }
       if (XMODE == 1) {
-        w0[u] = *reinterpret_cast<const float4*>(nrow + ks * 32);
-        w1[u] = *reinterpret_cast<const float4*>(nrow + ks * 32 + 4);
+        w0[u] = *reinterpret_cast<const float4*>(nrow + ko);
+        w1[u] = *reinterpret_cast<const float4*>(nrow + ko + 4);
       }
     }
 #pragma unroll
@@ -137,6 +155,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
       }
     }
   }
+#if (Q3A_SK_EXP & 4)
+  if (wave == 0 && n0 + kc * 4 < a.N) {  // experiment: no cross-wave reduction, wave 0 stores its partial
+    for (int h = 0; h < SH; ++h)
+      for (int r = 0; r < 4; ++r) a.out[(size_t)(h * 16 + l15) * a.ldo + n0 + kc * 4 + r] = acc[0][h][r];
+  }
+  return;
+#endif
   // D[row i][sequence j] of v_mfma_f32_16x16x32: j = lane&15, i = (lane>>4)*4 + r
 #pragma unroll
   for (int t = 0; t < TILES; ++t)
@@ -155,7 +180,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   }
   __syncthreads();
   // ---- fixed-order reduction of the K-slices + epilogue: thread -> (row i, sequence s) ----
-  const int i = tid >> 5, s = tid & 31;  // 16 rows x 32 sequences = 512 threads
+  // 16 rows x 32 sequences = 512 threads; 16 consecutive lanes own the 16 consecutive output columns of one sequence
+  // (64-B runs; with the sequence as the fast index every lane hit its own line: 4 KB stride)
+  const int i = tid & 15, s = tid >> 4;
   if (s >= a.S || (SH == 1 && s >= 16)) return;
   const int sh = SH == 1 ? 0 : s >> 4, sj = s & 15;
   float v[TILES];
@@ -190,17 +217,27 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   }
 }
 
-template <bool SPLIT, int XMODE>
-void launch_s(const SkinnyArgs& a, hipStream_t s) {
+template <bool SPLIT, int XMODE, int UNR>
+void launch_u(const SkinnyArgs& a, hipStream_t s) {
   const dim3 block(SK_WAVES * 64);
   if (a.mode == 2) {
     const dim3 grid((a.N + 31) / 32);
-    if (a.S <= 16) hipLaunchKernelGGL((skinny_kernel<SPLIT, 2, 1, XMODE>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((skinny_kernel<SPLIT, 2, 2, XMODE>), grid, block, 0, s, a);
+    if (a.S <= 16) hipLaunchKernelGGL((skinny_kernel<SPLIT, 2, 1, XMODE, UNR>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((skinny_kernel<SPLIT, 2, 2, XMODE, UNR>), grid, block, 0, s, a);
   } else {
     const dim3 grid((a.N + 15) / 16);
-    if (a.S <= 16) hipLaunchKernelGGL((skinny_kernel<SPLIT, 1, 1, XMODE>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((skinny_kernel<SPLIT, 1, 2, XMODE>), grid, block, 0, s, a);
+    if (a.S <= 16) hipLaunchKernelGGL((skinny_kernel<SPLIT, 1, 1, XMODE, UNR>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((skinny_kernel<SPLIT, 1, 2, XMODE, UNR>), grid, block, 0, s, a);
+  }
+}
+template <bool SPLIT, int XMODE>
+void launch_s(const SkinnyArgs& a, hipStream_t s) {
+  const int per = (a.K / 32 + SK_WAVES - 1) / SK_WAVES;  // k-steps per wave
+  // registers per step and lane: 4 (W) x tiles + 4 (bf16 x) or 8..16 (fp32 x [+ norm weight]) x sequence halves
+  if constexpr (XMODE == 2) {
+    if (per <= 4) launch_u<SPLIT, XMODE, 4>(a, s); else if (per <= 8) launch_u<SPLIT, XMODE, 8>(a, s); else launch_u<SPLIT, XMODE, 12>(a, s);
+  } else {
+    if (per <= 4) launch_u<SPLIT, XMODE, 4>(a, s); else launch_u<SPLIT, XMODE, 6>(a, s);
   }
 }
 

@@ -7,6 +7,7 @@
 #include <vector>
 #include "k_gemv.hip"  // the product GEMV kernels, timed in the same harness (compile with -I qwen3_asr_rs_amd/csrc)
 #include "k_dattn.hip"
+#include "k_skinny.hip"
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -183,6 +184,32 @@ int main() {
           const char* e = q3a::launch_gemv(a, 1, s);
           if (e) printf("launch_gemv: %s\n", e);
         }, (double)N * K * 2)) return 1;
+  }
+  // skinny MFMA GEMM (k_skinny.hip), 32 sequences, the decode shapes of the 0.6B model
+  {
+    float *xf, *yf, *rmsw;
+    uint16_t* xh;
+    CHK(hipMalloc(&xf, 32 * 4096 * 4)); CHK(hipMalloc(&yf, 32 * 6144 * 4)); CHK(hipMalloc(&xh, 32 * 4096 * 2)); CHK(hipMalloc(&rmsw, 4096 * 4));
+    CHK(hipMemset(xf, 0, 32 * 4096 * 4)); CHK(hipMemset(yf, 0, 32 * 6144 * 4)); CHK(hipMemset(xh, 0, 32 * 4096 * 2)); CHK(hipMemset(rmsw, 0, 4096 * 4));
+    struct Cfg { const char* name; int N, K, mode, xmode; };
+    const Cfg cfgs[] = {{"qkv  N=4096 K=1024 fp32 x + fused norm", 4096, 1024, 0, 1}, {"qkv  N=4096 K=1024 fp32 x", 4096, 1024, 0, 0},
+                        {"qkv  N=4096 K=1024 bf16 x", 4096, 1024, 0, 2}, {"gateup N=6144 K=1024 GLU fused norm", 6144, 1024, 2, 1},
+                        {"o    N=1024 K=2048 bf16 x resid", 1024, 2048, 1, 2}, {"down N=1024 K=3072 bf16 x resid", 1024, 3072, 1, 2},
+                        {"down N=1024 K=3072 fp32 x resid", 1024, 3072, 1, 0}};
+    for (const Cfg& c : cfgs) {
+      const double bytes = (double)c.N * c.K * 2;
+      const size_t stride = (size_t)c.N * c.K;
+      const int slots = (int)(WB / 2 / stride);
+      char name[96];
+      snprintf(name, sizeof name, "skinny S=32 %s (%.1f MB)", c.name, bytes * 1e-6);
+      if (time_graph(name, n, s, [&](int i) {
+            q3a::SkinnyArgs a{};
+            a.x = xf; a.x16 = c.xmode == 2 ? xh : nullptr; a.ldx = c.K; a.S = 32; a.rms_w = c.xmode == 1 ? rmsw : nullptr; a.eps = 1e-6f;
+            a.W = W + (size_t)(i % slots) * stride; a.N = c.N; a.K = c.K; a.mode = c.mode; a.out = yf; a.ldo = c.mode == 2 ? c.N / 2 : c.N; a.resid = yf;
+            const char* e = q3a::launch_skinny(a, false, s);
+            if (e) printf("launch_skinny: %s\n", e);
+          }, bytes)) return 1;
+    }
   }
   // decode attention (k_dattn.hip): 16 q heads / 8 kv heads, context 450 of 512, cold bf16 cache (cycled through W)
   {
