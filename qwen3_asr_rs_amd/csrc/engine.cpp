@@ -492,8 +492,9 @@ struct q3a_engine {
     rope_cur.ensure((size_t)b * 128 * 4);
     x_dec.ensure((size_t)b * H * 4); next_tok.ensure((size_t)b * 4); forced_tok.ensure((size_t)b * 4);
     out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
-    s_ln.ensure((size_t)b * H * 4); s_qkv.ensure((size_t)b * d.qkv_dim() * 4); s_ctx.ensure((size_t)b * d.q_dim() * 4);
-    s_act.ensure((size_t)b * d.inter * 4); logits.ensure((size_t)b * d.vocab * 4);
+    // s_ctx / s_act also hold the bf16 fragment-order copies of the skinny GEMM path: always 32 sequences there
+    s_ln.ensure((size_t)b * H * 4); s_qkv.ensure((size_t)b * d.qkv_dim() * 4); s_ctx.ensure((size_t)std::max(b, 16) * d.q_dim() * 4);
+    s_act.ensure((size_t)std::max(b, 16) * d.inter * 4); logits.ensure((size_t)b * d.vocab * 4);
     part_stride = std::max(128, (d.vocab + 3) / 4);  // >= blocks of the lm_head GEMV at 1 row per wave
     part_val.ensure((size_t)b * part_stride * 4); part_idx.ensure((size_t)b * part_stride * 4);
     attn_nsplit = (max_ctx + dattn_keys_per_split(kv_f32()) - 1) / dattn_keys_per_split(kv_f32());
@@ -672,17 +673,17 @@ struct q3a_engine {
         // skinny MFMA GEMMs: the norms are fused (no norm launches), and in the default mode the two K-heavy
         // projections read bf16 activations written by their producers (attention merge, SwiGLU epilogue)
         const bool b16 = !precise();
-        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream, b16 ? s_ctx.as<uint16_t>() : nullptr)); });
+        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream, b16 ? s_ctx.as<uint16_t>() : nullptr, b16)); });
         SkinnyArgs o{};
-        o.x = s_ctx.as<float>(); o.x16 = b16 ? s_ctx.as<uint16_t>() : nullptr; o.ldx = QD; o.S = S; o.W = wh(l.o_w); o.N = H; o.K = QD;
+        o.x = s_ctx.as<float>(); o.x16 = b16 ? s_ctx.as<uint16_t>() : nullptr; o.x16_frag = b16; o.ldx = QD; o.S = S; o.W = wh(l.o_w); o.N = H; o.K = QD;
         o.bias = o_bias ? wf(l.o_b) : nullptr; o.mode = 1; o.out = x_dec.as<float>(); o.ldo = H; o.resid = x_dec.as<float>();
         timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { KCHK(launch_skinny(o, precise(), stream)); });
         SkinnyArgs u{};
         u.x = x_dec.as<float>(); u.ldx = H; u.S = S; u.rms_w = wf(l.post_ln); u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
-        u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act.as<float>(); u.out16 = b16 ? s_act.as<uint16_t>() : nullptr; u.ldo = I;
+        u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act.as<float>(); u.out16 = b16 ? s_act.as<uint16_t>() : nullptr; u.out16_frag = b16; u.ldo = I;
         timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_skinny(u, precise(), stream)); });
         SkinnyArgs dn{};
-        dn.x = s_act.as<float>(); dn.x16 = b16 ? s_act.as<uint16_t>() : nullptr; dn.ldx = I; dn.S = S; dn.W = wh(l.down_w); dn.N = H; dn.K = I;
+        dn.x = s_act.as<float>(); dn.x16 = b16 ? s_act.as<uint16_t>() : nullptr; dn.x16_frag = b16; dn.ldx = I; dn.S = S; dn.W = wh(l.down_w); dn.N = H; dn.K = I;
         dn.bias = mlp_bias ? wf(l.down_b) : nullptr; dn.mode = 1; dn.out = x_dec.as<float>(); dn.ldo = H; dn.resid = x_dec.as<float>();
         timed(Q3A_KC_GEMM, 2.0 * H * I, [&] { KCHK(launch_skinny(dn, precise(), stream)); });
       } else {

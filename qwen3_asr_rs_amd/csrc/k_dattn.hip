@@ -229,7 +229,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
 // merge of the split partials into [S][n_q*128] (only the GEMM decode path needs it as a separate launch)
 __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
                                                            const float* __restrict__ po, int nsplit, float* __restrict__ out,
-                                                           uint16_t* __restrict__ out16) {
+                                                           uint16_t* __restrict__ out16, int n_q, int frag) {
   const size_t sh = blockIdx.x;  // (sequence, head) flattened
   const int d = threadIdx.x;
   float M = -INFINITY;
@@ -242,8 +242,12 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restri
     L += pl[sh * nsplit + sp] * f;
     o += po[(sh * nsplit + sp) * 128 + d] * f;
   }
-  if (out16) out16[sh * 128 + d] = (uint16_t)f32_to_bf16_bits(o / L);  // feeds the bf16-x skinny GEMM (o_proj)
-  else out[sh * 128 + d] = o / L;
+  if (out16) {  // feeds the bf16-x skinny GEMM (o_proj), optionally in its fragment order
+    const int s = (int)(sh / n_q), k = (int)(sh % n_q) * 128 + d;
+    out16[frag ? skinny_frag_index(s, k) : sh * 128 + d] = (uint16_t)f32_to_bf16_bits(o / L);
+  } else {
+    out[sh * 128 + d] = o / L;
+  }
 }
 
 }  // namespace
@@ -267,9 +271,10 @@ const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipS
 }
 
 const char* launch_attn_combine(const float* pm, const float* pl, const float* po, int nsplit, int S, int n_q, float* out,
-                                hipStream_t s, uint16_t* out16) {
+                                hipStream_t s, uint16_t* out16, bool frag) {
   if (S <= 0) return nullptr;
-  hipLaunchKernelGGL(attn_combine_kernel, dim3(S * n_q), dim3(128), 0, s, pm, pl, po, nsplit, out, out16);
+  if (frag && S > 32) return "attn_combine: fragment order holds at most 32 sequences";
+  hipLaunchKernelGGL(attn_combine_kernel, dim3(S * n_q), dim3(128), 0, s, pm, pl, po, nsplit, out, out16, n_q, frag ? 1 : 0);
   return nullptr;
 }
 

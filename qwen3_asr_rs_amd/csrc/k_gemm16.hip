@@ -396,7 +396,8 @@ const char* launch_gemm16(const uint16_t* X, int lda, const uint16_t* W, int M, 
     else hipLaunchKernelGGL((gemm16k_kernel<32, 128, DenseA16>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
     return nullptr;
   }
-  if (K % 64 == 0) {
+  static const bool force_bk32 = [] { const char* e = getenv("Q3A_GEMM16_BK32"); return e && atoi(e) != 0; }();  // A/B knob
+  if (K % 64 == 0 && !force_bk32) {
     if (glu) launch_sized16<64, true>(A, W, M, N, K, ep, s); else launch_sized16<64, false>(A, W, M, N, K, ep, s);
   } else {
     if (glu) launch_sized16<32, true>(A, W, M, N, K, ep, s); else launch_sized16<32, false>(A, W, M, N, K, ep, s);

@@ -116,7 +116,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #if (Q3A_SK_EXP & 1)
           xq[u][h] = make_uint4(ks, lane, 0u, 0u);
 #else
-          xq[u][h] = *reinterpret_cast<const uint4*>(xrow16[h] + ko);
+          // fragment order (kernels.h skinny_frag_index): lane-linear, 1 KiB contiguous per (k-step, sequence half)
+          const uint16_t* xp = a.x16_frag ? a.x16 + ((((size_t)ks * 2 + h) * 4 + kc) * 16 + l15) * 8 : xrow16[h] + ko;
+          xq[u][h] = *reinterpret_cast<const uint4*>(xp);
 #endif
         } else {
           x0[u][h] = *reinterpret_cast<const float4*>(xrow[h] + ko);
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     float g = v[0], u = v[TILES - 1];
     if (a.bias) { g += a.bias[n0 + i]; u += a.bias[n0 + 16 + i]; }
     const float y = silu_f(g) * u;
-    if (a.out16) a.out16[(size_t)s * a.ldo + (n0 >> 1) + i] = (uint16_t)f32_to_bf16_bits(y);
+    if (a.out16) a.out16[a.out16_frag ? skinny_frag_index(s, (n0 >> 1) + i) : (size_t)s * a.ldo + (n0 >> 1) + i] = (uint16_t)f32_to_bf16_bits(y);
     else a.out[(size_t)s * a.ldo + (n0 >> 1) + i] = y;
   }
 }

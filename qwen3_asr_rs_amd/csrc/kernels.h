@@ -134,6 +134,8 @@ int gemv_rows_per_wave(const GemvArgs& a);
 struct SkinnyArgs {
   const float* x; int ldx; int S;   // [S][K] fp32 ...
   const uint16_t* x16;              // ... or, when non-null, the same as bf16 (default mode: written by the producer)
+  int x16_frag;                     // x16 is in MFMA-fragment order (skinny_frag_index) instead of row-major [S][K]
+  int out16_frag;                   // out16 is written in that order (for the next skinny GEMM)
   const float* rms_w; float eps;    // non-null (fp32 x only): RMSNorm fused -- x*w enters the MFMA, rstd scales the result
   const uint16_t* W; int N; int K;  // bf16 [N][K]
   const float* bias;                // [N] or null
@@ -143,6 +145,13 @@ struct SkinnyArgs {
   const float* resid;
 };
 const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s);
+// Fragment order of a bf16 activation matrix for up to 32 sequences: the 16 B that lane (sequence s & 15, k-chunk
+// (k >> 3) & 3) of a v_mfma_f32_16x16x32_bf16 B operand needs for k-step k >> 5 and sequence half s >> 4 sit at
+// lane-linear offsets, so one wave load is 1 KiB contiguous (8 cache lines) instead of 16 rows x 64 B (16 lines).
+// Buffers in this order always hold 32 sequences: 32 * K elements.
+__host__ __device__ inline size_t skinny_frag_index(int s, int k) {
+  return ((((size_t)(k >> 5) * 2 + (s >> 4)) * 4 + ((k >> 3) & 3)) * 16 + (s & 15)) * 8 + (k & 7);
+}
 
 struct DecodeAttnArgs {
   const float* qkv;            // [S][qkv_dim] fp32 (raw projections of the current token)
@@ -161,7 +170,8 @@ inline int dattn_keys_per_split(bool kv_f32) { return kv_f32 ? DATTN_KEYS_PER_SP
 const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
 // out[S][n_q*128] = merged partials (needed as its own launch only on the GEMM decode path)
 const char* launch_attn_combine(const float* pm, const float* pl, const float* po, int nsplit, int S, int n_q, float* out,
-                                hipStream_t s, uint16_t* out16 = nullptr);  // out16 != null: bf16 there instead of out
+                                hipStream_t s, uint16_t* out16 = nullptr, bool frag = false);
+// out16 != null: bf16 there instead of out; frag: in skinny_frag_index order (S <= 32)
 
 struct FinalizeArgs {
   const float* part_val;   // [S][part_stride] block-partial maxima ...

@@ -195,7 +195,9 @@ int main() {
     const Cfg cfgs[] = {{"qkv  N=4096 K=1024 fp32 x + fused norm", 4096, 1024, 0, 1}, {"qkv  N=4096 K=1024 fp32 x", 4096, 1024, 0, 0},
                         {"qkv  N=4096 K=1024 bf16 x", 4096, 1024, 0, 2}, {"gateup N=6144 K=1024 GLU fused norm", 6144, 1024, 2, 1},
                         {"o    N=1024 K=2048 bf16 x resid", 1024, 2048, 1, 2}, {"down N=1024 K=3072 bf16 x resid", 1024, 3072, 1, 2},
-                        {"down N=1024 K=3072 fp32 x resid", 1024, 3072, 1, 0}};
+                        {"down N=1024 K=3072 fp32 x resid", 1024, 3072, 1, 0},
+                        {"o    N=1024 K=2048 bf16 x fragment order", 1024, 2048, 1, 3}, {"down N=1024 K=3072 bf16 x fragment order", 1024, 3072, 1, 3},
+                        {"qkv  N=4096 K=1024 bf16 x fragment order", 4096, 1024, 0, 3}};
     for (const Cfg& c : cfgs) {
       const double bytes = (double)c.N * c.K * 2;
       const size_t stride = (size_t)c.N * c.K;
@@ -204,7 +206,7 @@ int main() {
       snprintf(name, sizeof name, "skinny S=32 %s (%.1f MB)", c.name, bytes * 1e-6);
       if (time_graph(name, n, s, [&](int i) {
             q3a::SkinnyArgs a{};
-            a.x = xf; a.x16 = c.xmode == 2 ? xh : nullptr; a.ldx = c.K; a.S = 32; a.rms_w = c.xmode == 1 ? rmsw : nullptr; a.eps = 1e-6f;
+            a.x = xf; a.x16 = c.xmode >= 2 ? xh : nullptr; a.x16_frag = c.xmode == 3; a.ldx = c.K; a.S = 32; a.rms_w = c.xmode == 1 ? rmsw : nullptr; a.eps = 1e-6f;
             a.W = W + (size_t)(i % slots) * stride; a.N = c.N; a.K = c.K; a.mode = c.mode; a.out = yf; a.ldo = c.mode == 2 ? c.N / 2 : c.N; a.resid = yf;
             const char* e = q3a::launch_skinny(a, false, s);
             if (e) printf("launch_skinny: %s\n", e);
