@@ -127,7 +127,7 @@ def main():
     prof = eng.profile_decode_step()  # per-launch HIP events on the engine's stream, one eager decode step
     # dominant kernel (largest share of kernel time in the rocprofv3 trace): the qkv / gate-up GEMV instance.
     # Timed live with ONE HIP event pair around back-to-back launches that sweep all layers' matrices.
-    stream_prof = eng.profile_weight_stream(reps=4) if B <= 4 else None
+    stream_prof = eng.profile_weight_stream(reps=4) if B <= 2 else None  # GEMV path: 1-2 sequences
 
     if rank == 0:
         audio_seconds = world * B * args.seconds * args.steps
@@ -136,7 +136,7 @@ def main():
             bytes_per_launch, avg_us, n_launch = stream_prof["bytes_per_launch"], stream_prof["avg_us"], 56
         else:
             g = prof["gemm"]
-            kname = "gemm_kernel (batched decode projections)"
+            kname = "skinny_kernel (batched decode projections, event-timed eagerly)"
             bytes_per_launch = g["weight_bytes"] / max(g["launches"], 1)
             avg_us, n_launch = g["total_us"] / max(g["launches"], 1), g["launches"]
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
