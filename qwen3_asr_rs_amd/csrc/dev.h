@@ -39,6 +39,26 @@ __device__ __forceinline__ uint4 ld_stream16(const void* p) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Cross-row exchanges on gfx950 without the LDS crossbar (ds_bpermute: address VALU + LDS op + wait per value):
+// v_permlane16_swap / v_permlane32_swap with both operands equal leave lane l with its own value in one result and
+// the value of lane l^16 / l^32 in the other, so an xor-16 / xor-32 all-reduce step is one swap + one op.
+__device__ __forceinline__ float xor16_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -69,10 +89,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 __device__ __forceinline__ float lane_bcast(float v, int lane_uniform) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
 }
-// full-wave sum without LDS traffic: 4 DPP adds + 4 v_readlane
+// full-wave sum without LDS traffic: 4 DPP adds inside the rows, then the two permlane-swap steps across them.
+// Every lane ends with the same bits: (r0 + r1) + (r2 + r3) up to commutation.
 __device__ __forceinline__ float wave_sum_fast(float v) {
   v = row16_sum(v);
-  return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+  return xor32_sum(xor16_sum(v));
 }
 
 // One wave per 128-wide head vector; the lane owns dims (lane, lane+64) = the rotate_half partners.

@@ -130,6 +130,11 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   __syncthreads();
 
   // ---- scores for this wave's 16 keys ----
+  // This section is VALU work on the critical path (a wave64 VALU instruction occupies its SIMD for 4 cycles and two
+  // waves share a SIMD): one reciprocal instead of a division per score, the hardware exponential in the default
+  // mode (the precise mode keeps expf), permlane swaps instead of ds_bpermute for the cross-row steps.
+  const float inv_scale = 1.0f / a.scale_div;
+  auto expw = [](float x) { return sizeof(KVT) == 4 ? expf(x) : __expf(x); };
   float qf[GROUP][DPL];
 #pragma unroll
   for (int g = 0; g < GROUP; ++g)
@@ -151,8 +156,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
 #pragma unroll
       for (int e = 0; e < DPL; ++e) p += qf[g][e] * kf[e];
       p = row16_sum(p);
-      if (LPK == 32) p += __shfl_xor(p, 16, 64);
-      sc[i][g] = (key <= pos) ? p / a.scale_div : -INFINITY;  // layers.rs:327-328 divides after the matmul
+      if (LPK == 32) p = xor16_sum(p);
+      sc[i][g] = (key <= pos) ? p * inv_scale : -INFINITY;  // layers.rs:327-328 scales after the matmul
     }
   }
   float acc[GROUP][DPL], mw[GROUP], lw[GROUP];
@@ -161,8 +166,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
     float mx = sc[0][g];
 #pragma unroll
     for (int i = 1; i < NI; ++i) mx = fmaxf(mx, sc[i][g]);
-    if (LPK == 16) mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (LPK == 16) mx = xor16_max(mx);
+    mx = xor32_max(mx);
     mw[g] = mx;  // -inf when none of this wave's keys exists yet
     lw[g] = 0.f;
 #pragma unroll
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
     }
 #pragma unroll
     for (int g = 0; g < GROUP; ++g) {
-      const float p = (key <= pos) ? expf(sc[i][g] - mw[g]) : 0.f;
+      const float p = (key <= pos) ? expw(sc[i][g] - mw[g]) : 0.f;
       lw[g] += p;
 #pragma unroll
       for (int e = 0; e < DPL; ++e) acc[g][e] += p * vf[e];
@@ -191,12 +196,12 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   // fold the KPI key columns of the wave (lanes with equal `sub`)
 #pragma unroll
   for (int g = 0; g < GROUP; ++g) {
-    if (LPK == 16) lw[g] += __shfl_xor(lw[g], 16, 64);
-    lw[g] += __shfl_xor(lw[g], 32, 64);
+    if (LPK == 16) lw[g] = xor16_sum(lw[g]);
+    lw[g] = xor32_sum(lw[g]);
 #pragma unroll
     for (int e = 0; e < DPL; ++e) {
-      if (LPK == 16) acc[g][e] += __shfl_xor(acc[g][e], 16, 64);
-      acc[g][e] += __shfl_xor(acc[g][e], 32, 64);
+      if (LPK == 16) acc[g][e] = xor16_sum(acc[g][e]);
+      acc[g][e] = xor32_sum(acc[g][e]);
     }
     if (lane == 0) { cm[wave][g] = mw[g]; cl[wave][g] = lw[g]; }
     if (kq == 0) {
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
     float L = 0.f, o0 = 0.f, o1 = 0.f;
 #pragma unroll
     for (int w = 0; w < DA_WAVES; ++w) {
-      const float f = (cm[w][g] == -INFINITY) ? 0.f : expf(cm[w][g] - M);
+      const float f = (cm[w][g] == -INFINITY) ? 0.f : expw(cm[w][g] - M);
       L += cl[w][g] * f;
       o0 += co[w][g][lane] * f;
       o1 += co[w][g][lane + 64] * f;
