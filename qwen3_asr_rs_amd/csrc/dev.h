@@ -7,6 +7,7 @@ namespace q3a {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;  // MFMA 16x16x32 bf16 A/B operand (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 accumulator
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;    // operand of the packed VALU ops (v_pk_fma_f32)
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // MFMA 32x32 accumulator
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t v) { return __uint_as_float(v << 16); }

@@ -55,8 +55,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   constexpr int KEYS_PER_SPLIT = KEYS_PER_WAVE * DA_WAVES;  // 128
   static_assert(KEYS_PER_SPLIT == (sizeof(KVT) == 2 ? DATTN_KEYS_PER_SPLIT_BF16 : DATTN_KEYS_PER_SPLIT_F32), "split size");
   __shared__ float q_s[GROUP][128];
-  __shared__ float k_s[128];
-  __shared__ float v_s[128];
+  __shared__ __attribute__((aligned(16))) KVT k_s[128];  // the new token's k / v row in cache format
+  __shared__ __attribute__((aligned(16))) KVT v_s[128];
   __shared__ float cm[DA_WAVES][GROUP], cl[DA_WAVES][GROUP];
   __shared__ float co[DA_WAVES][GROUP][128];
   const int kvh = blockIdx.x, s = blockIdx.y, sp = blockIdx.z;
@@ -119,13 +119,13 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   } else if (owner && wave == GROUP) {
     KvIo<KVT>::store(kc + (size_t)pos * 128 + lane, x1);
     KvIo<KVT>::store(kc + (size_t)pos * 128 + lane + 64, x2);
-    k_s[lane] = KvIo<KVT>::round(x1);
-    k_s[lane + 64] = KvIo<KVT>::round(x2);
+    KvIo<KVT>::store(&k_s[lane], x1);
+    KvIo<KVT>::store(&k_s[lane + 64], x2);
   } else if (owner && wave == GROUP + 1) {
     KvIo<KVT>::store(vc + (size_t)pos * 128 + lane, x1);
     KvIo<KVT>::store(vc + (size_t)pos * 128 + lane + 64, x2);
-    v_s[lane] = KvIo<KVT>::round(x1);
-    v_s[lane + 64] = KvIo<KVT>::round(x2);
+    KvIo<KVT>::store(&v_s[lane], x1);
+    KvIo<KVT>::store(&v_s[lane + 64], x2);
   }
   __syncthreads();
 
@@ -135,32 +135,35 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   // mode (the precise mode keeps expf), permlane swaps instead of ds_bpermute for the cross-row steps.
   const float inv_scale = 1.0f / a.scale_div;
   auto expw = [](float x) { return sizeof(KVT) == 4 ? expf(x) : __expf(x); };
-  float qf[GROUP][DPL];
+  // The multiply-adds run two lanes wide (v_pk_fma_f32 on float pairs).  The new token's own k / v row and the rows
+  // beyond it are patched into the raw 16-B registers (4 selects) rather than into the unpacked floats (8).
+  f32x2_t qf[GROUP][DPL / 2];
 #pragma unroll
   for (int g = 0; g < GROUP; ++g)
 #pragma unroll
-    for (int e = 0; e < DPL; ++e) qf[g][e] = q_s[g][sub * DPL + e];
+    for (int e = 0; e < DPL / 2; ++e) qf[g][e] = f32x2_t{q_s[g][sub * DPL + 2 * e], q_s[g][sub * DPL + 2 * e + 1]};
+  const uint4 k_new = *reinterpret_cast<const uint4*>(&k_s[sub * DPL]), v_new = *reinterpret_cast<const uint4*>(&v_s[sub * DPL]);
   float sc[NI][GROUP];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int key = key_base + i * KPI;
+    if (key == pos) { kraw[i] = k_new; vraw[i] = v_new; }
+    if (key > pos) vraw[i] = make_uint4(0u, 0u, 0u, 0u);  // stale cache row (possibly NaN bits): p is 0 there, keep 0 * v finite
     float kf[DPL];
     Frag16<KVT>::unpack(kraw[i], kf);
-    if (key == pos) {
-#pragma unroll
-      for (int e = 0; e < DPL; ++e) kf[e] = k_s[sub * DPL + e];
-    }
 #pragma unroll
     for (int g = 0; g < GROUP; ++g) {
-      float p = 0.f;
+      f32x2_t p2 = qf[g][0] * f32x2_t{kf[0], kf[1]};
 #pragma unroll
-      for (int e = 0; e < DPL; ++e) p += qf[g][e] * kf[e];
+      for (int e = 1; e < DPL / 2; ++e) p2 += qf[g][e] * f32x2_t{kf[2 * e], kf[2 * e + 1]};
+      float p = p2.x + p2.y;
       p = row16_sum(p);
       if (LPK == 32) p = xor16_sum(p);
       sc[i][g] = (key <= pos) ? p * inv_scale : -INFINITY;  // layers.rs:327-328 scales after the matmul
     }
   }
-  float acc[GROUP][DPL], mw[GROUP], lw[GROUP];
+  f32x2_t acc[GROUP][DPL / 2];
+  float mw[GROUP], lw[GROUP];
 #pragma unroll
   for (int g = 0; g < GROUP; ++g) {
     float mx = sc[0][g];
@@ -171,26 +174,19 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
     mw[g] = mx;  // -inf when none of this wave's keys exists yet
     lw[g] = 0.f;
 #pragma unroll
-    for (int e = 0; e < DPL; ++e) acc[g][e] = 0.f;
+    for (int e = 0; e < DPL / 2; ++e) acc[g][e] = f32x2_t{0.f, 0.f};
   }
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int key = key_base + i * KPI;
     float vf[DPL];
     Frag16<KVT>::unpack(vraw[i], vf);
-    if (key == pos) {
-#pragma unroll
-      for (int e = 0; e < DPL; ++e) vf[e] = v_s[sub * DPL + e];
-    } else if (key > pos) {  // stale cache row (possibly NaN bits): p is 0 there, keep 0 * v finite
-#pragma unroll
-      for (int e = 0; e < DPL; ++e) vf[e] = 0.f;
-    }
 #pragma unroll
     for (int g = 0; g < GROUP; ++g) {
       const float p = (key <= pos) ? expw(sc[i][g] - mw[g]) : 0.f;
       lw[g] += p;
 #pragma unroll
-      for (int e = 0; e < DPL; ++e) acc[g][e] += p * vf[e];
+      for (int e = 0; e < DPL / 2; ++e) acc[g][e] += f32x2_t{p, p} * f32x2_t{vf[2 * e], vf[2 * e + 1]};
     }
   }
   // fold the KPI key columns of the wave (lanes with equal `sub`)
@@ -198,15 +194,17 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   for (int g = 0; g < GROUP; ++g) {
     if (LPK == 16) lw[g] = xor16_sum(lw[g]);
     lw[g] = xor32_sum(lw[g]);
+    float af[DPL];
 #pragma unroll
     for (int e = 0; e < DPL; ++e) {
-      if (LPK == 16) acc[g][e] = xor16_sum(acc[g][e]);
-      acc[g][e] = xor32_sum(acc[g][e]);
+      af[e] = (e & 1) ? acc[g][e >> 1].y : acc[g][e >> 1].x;
+      if (LPK == 16) af[e] = xor16_sum(af[e]);
+      af[e] = xor32_sum(af[e]);
     }
     if (lane == 0) { cm[wave][g] = mw[g]; cl[wave][g] = lw[g]; }
     if (kq == 0) {
 #pragma unroll
-      for (int e = 0; e < DPL; ++e) co[wave][g][sub * DPL + e] = acc[g][e];
+      for (int e = 0; e < DPL; ++e) co[wave][g][sub * DPL + e] = af[e];
     }
   }
   __syncthreads();

@@ -151,10 +151,13 @@ __device__ __forceinline__ void gemv_rows(const GemvArgs& a, int g, int (&prow)[
   }
 }
 
+// 8 weights x 8 activations; the multiply-adds run two wide (v_pk_fma_f32): 8 unpack + 4 packed FMA + 2 adds
 __device__ __forceinline__ float dot8(const uint4& w, const float (&x)[8], float s) {
-  s += bf16lo(w.x) * x[0]; s += bf16hi(w.x) * x[1]; s += bf16lo(w.y) * x[2]; s += bf16hi(w.y) * x[3];
-  s += bf16lo(w.z) * x[4]; s += bf16hi(w.z) * x[5]; s += bf16lo(w.w) * x[6]; s += bf16hi(w.w) * x[7];
-  return s;
+  f32x2_t a = f32x2_t{bf16lo(w.x), bf16hi(w.x)} * f32x2_t{x[0], x[1]};
+  a += f32x2_t{bf16lo(w.y), bf16hi(w.y)} * f32x2_t{x[2], x[3]};
+  a += f32x2_t{bf16lo(w.z), bf16hi(w.z)} * f32x2_t{x[4], x[5]};
+  a += f32x2_t{bf16lo(w.w), bf16hi(w.w)} * f32x2_t{x[6], x[7]};
+  return s + (a.x + a.y);
 }
 
 // epilogue shared by both variants; acc holds the finished (rstd-scaled) dot products, valid on every lane
