@@ -658,7 +658,7 @@ struct q3a_engine {
         GemvArgs g{};
         if (std::min(S, 4) * d.n_q * attn_nsplit <= GEMV_ATTN_MAX_TABLE) {  // merge the key splits inside the o_proj GEMV
           g.attn_pm = attn_pm.as<float>(); g.attn_pl = attn_pl.as<float>(); g.attn_po = attn_po.as<float>();
-          g.attn_nsplit = attn_nsplit; g.attn_heads = d.n_q;
+          g.attn_nsplit = attn_nsplit; g.attn_heads = d.n_q; g.attn_fast_exp = precise() ? 0 : 1;
         } else {  // very long contexts: separate merge launch
           timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream)); });
           g.x = s_ctx.as<float>();
