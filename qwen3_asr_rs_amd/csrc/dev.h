@@ -11,15 +11,16 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;    // operand of the 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // MFMA 32x32 accumulator
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t v) { return __uint_as_float(v << 16); }
-// round-to-nearest-even (inputs are finite activations)
-__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+// fp32 -> bf16, round-to-nearest-even: one v_cvt_pk_bf16_f32 per PAIR on gfx950 (the integer formulation --
+// add 0x7fff + lsb, shift -- costs ~5 VALU instructions per value, and a wave64 VALU instruction holds its SIMD for
+// 4 cycles: in the conversion-heavy kernels (skinny GEMM with fp32 x, attention P packing, bf16 epilogues) that was
+// a large share of the issue slots)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) { return pack_bf16x2(f, 0.f) & 0xffffu; }
 // two bf16 packed in one dword -> two floats
 __device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }

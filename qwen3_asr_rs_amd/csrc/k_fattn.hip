@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
     }
   };
 
+  const float inv_scale = 1.0f / a.scale_div;  // one reciprocal instead of a division per score
   load_tile(0);
   for (int t = 0; t < n_tiles; ++t) {
     __syncthreads();  // every wave is done with the previous tile
@@ -145,24 +146,24 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
       const bool valid = key < seg.len && (!CAUSAL || key <= qi);
-      sacc[r] = valid ? sacc[r] / a.scale_div : -INFINITY;
+      sacc[r] = valid ? sacc[r] * inv_scale : -INFINITY;
       tmax = fmaxf(tmax, sacc[r]);
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    tmax = xor32_max(tmax);
     const float m_new = fmaxf(mrun, tmax);
     float alpha = 1.f, psum = 0.f;
     if (m_new == -INFINITY) {  // nothing visible yet for this query (only for padding queries)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
     } else {
-      alpha = expf(mrun - m_new);
+      alpha = __expf(mrun - m_new);  // hardware exponential: this kernel is the default (bf16) mode only
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        sacc[r] = expf(sacc[r] - m_new);  // exp(-inf) = 0 for masked keys
+        sacc[r] = __expf(sacc[r] - m_new);  // exp(-inf) = 0 for masked keys
         psum += sacc[r];
       }
     }
-    psum += __shfl_xor(psum, 32, 64);
+    psum = xor32_sum(psum);
     lrun = lrun * alpha + psum;
     mrun = m_new;
     // ---- P^T fragments: k-step kk uses this lane's registers kk*8 .. kk*8+7 ----
@@ -177,8 +178,7 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
     // ---- O^T[d][query] = alpha * O^T + sum_key V[key][d] P[key][query] ----
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+      oacc[dt] *= alpha;  // vector op: packed multiplies
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         // contraction slot (half, e) <-> key 16*kk + 4*half + (e & 3) + 8*(e >> 2): same map as the P registers
