@@ -74,6 +74,18 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // erf-form GELU (reference: Tensor::gelu -> gelu("none"), src/tensor.rs:350-352)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// The same two activations for epilogues whose result is rounded to bf16 anyway (default mode): erff / expf + a
+// division cost 30-50 VALU instructions per element -- more issue slots than the whole K loop of a short-K GEMM tile.
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7) on the hardware exponential and reciprocal; the negative
+// branch uses erfc directly, so there is no 1 - (1 - tiny) cancellation.  |gelu_fast - gelu_erf| < 4e-7 * max(1, |x|).
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float pe = poly * __expf(-z * z);  // erfc(|x| / sqrt 2)
+  return 0.5f * x * (x >= 0.f ? 2.0f - pe : pe);
+}
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // SiLU (reference: Tensor::silu, src/tensor.rs:354-356)
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 

@@ -47,9 +47,8 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) acc += wp[kh * 3 + kw] * in_l[kh][ow * 2 + kw];  // (ow*2-1+kw)+1
-    const float g = gelu_erf(acc);
-    if (out16) out16[obase + e] = (uint16_t)f32_to_bf16_bits(g);  // default mode: bf16 map feeds conv2's LDS-DMA
-    else out[obase + e] = g;
+    if (out16) out16[obase + e] = (uint16_t)f32_to_bf16_bits(gelu_fast(acc));  // default mode: bf16 map feeds conv2's LDS-DMA
+    else out[obase + e] = gelu_erf(acc);
   }
 }
 

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(ALoader A, const uint16_t* 
           float v = acc[i][j][r];
           if (ep.bias) v += ep.bias[n];
           if (ep.addend) v += ep.addend[(size_t)(m % ep.addend_period) * ep.ldo + n];
-          if (ep.act == 1) v = gelu_erf(v);
+          if (ep.act == 1) v = gelu_fast(v);  // default mode: the result is rounded to bf16 (dev.h)
           if (ep.resid) v += ep.resid[(size_t)orow * ep.ldo + n];
           if (ep.out16) ep.out16[(size_t)orow * ep.ldo + n] = (uint16_t)f32_to_bf16_bits(v);
           else ep.out[(size_t)orow * ep.ldo + n] = v;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(ALoader A, const uint16_t* 
           if (nb + 16 + col_in >= N) continue;
           float g = acc[i][j][r], u = acc[i][j + 1][r];
           if (ep.bias) { g += ep.bias[nb + col_in]; u += ep.bias[nb + 16 + col_in]; }
-          const float v = silu_f(g) * u;
+          const float v = silu_fast(g) * u;
           if (ep.out16) ep.out16[(size_t)orow * ep.ldo + (nb >> 1) + col_in] = (uint16_t)f32_to_bf16_bits(v);
           else ep.out[(size_t)orow * ep.ldo + (nb >> 1) + col_in] = v;
         }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void gemm16k_kernel(ALoader A, const uint16_t*
       const float4 b = *reinterpret_cast<const float4*>(ep.addend + (size_t)(m % ep.addend_period) * ep.ldo + n);
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
     }
-    if (ep.act == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+    if (ep.act == 1) { v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w); }
     if (ep.resid) {
       const float4 b = *reinterpret_cast<const float4*>(ep.resid + (size_t)orow * ep.ldo + n);
       v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
