@@ -61,16 +61,28 @@ __device__ __forceinline__ float xor32_max(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// DPP inside the 16-lane rows, permlane swaps across them: no LDS crossbar, every lane gets the result
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x141>(v));
+  v = fmaxf(v, dpp_mov<0x140>(v));
   return v;
 }
+// Every lane ends with the same bits: (r0 + r1) + (r2 + r3) up to commutation.
+__device__ __forceinline__ float wave_sum_fast(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_fast(v); }
+__device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row16_max(v))); }
 
 // erf-form GELU (reference: Tensor::gelu -> gelu("none"), src/tensor.rs:350-352)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -89,25 +101,8 @@ __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgc
 // SiLU (reference: Tensor::silu, src/tensor.rs:354-356)
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
-// DPP sum over the 16 lanes of a row: every lane of the row ends up with the row total
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(v);  // row_half_mirror
-  v += dpp_mov<0x140>(v);  // row_mirror
-  return v;
-}
 __device__ __forceinline__ float lane_bcast(float v, int lane_uniform) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
-}
-// full-wave sum without LDS traffic: 4 DPP adds inside the rows, then the two permlane-swap steps across them.
-// Every lane ends with the same bits: (r0 + r1) + (r2 + r3) up to commutation.
-__device__ __forceinline__ float wave_sum_fast(float v) {
-  v = row16_sum(v);
-  return xor32_sum(xor16_sum(v));
 }
 
 // One wave per 128-wide head vector; the lane owns dims (lane, lane+64) = the rotate_half partners.

@@ -175,8 +175,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int h = 0; h < SH; ++h) {
       float v = ss[h];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);  // the four k-chunk lanes of this sequence
+      v = xor32_sum(xor16_sum(v));  // the four k-chunk lanes of this sequence
       if (kc == 0) ssp[wave][h][l15] = v;
     }
   }
