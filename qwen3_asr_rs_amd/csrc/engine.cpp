@@ -214,6 +214,7 @@ struct q3a_engine {
       fail("no HIP device available: libq3asr_hip has no CPU fallback (hipGetDeviceCount: " + std::string(hipGetErrorString(e)) + ")");
     if (dev < 0 || dev >= n_dev) fail("device index out of range");
     HIPCHK(hipSetDevice(dev));
+    KCHK(skinny_init());
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto& x : ev) HIPCHK(hipEventCreate(&x));
   }

@@ -20,6 +20,8 @@
 //   v_mfma_f32_16x16x32_bf16 -> D[row][sequence], sequences 0-15 and 16-31 share the A fragment.
 // The eight K-slices are summed through LDS in a fixed order (deterministic), then 1/rms, bias / residual /
 // SiLU(gate)*up are applied.
+#include <stdlib.h>
+
 #include "dev.h"
 #include "kernels.h"
 
@@ -27,6 +29,8 @@ namespace q3a {
 namespace {
 
 constexpr int SK_WAVES = 8;
+typedef const void __attribute__((address_space(1)))* sk_gptr_t;
+typedef void __attribute__((address_space(3)))* sk_lptr_t;
 #ifndef Q3A_SK_EXP
 #define Q3A_SK_EXP 0  // timing experiments of tools/launch_floor.hip only
 #endif
@@ -50,9 +54,15 @@ __device__ __forceinline__ float sq4(const float4& a) { return a.x * a.x + a.y *
 // TILES = 16-row weight tiles per workgroup (1, or 2 = gate + up); SH = 16-sequence halves (1: S <= 16, 2: S <= 32)
 // UNR = k-steps whose loads a wave issues before its first MFMA: the launcher picks it to cover the wave's whole K
 // slice (K/8: 4 steps at K = 1024, 12 at K = 3072), so a wave makes ONE memory round trip, not K/8/4 of them
-template <bool SPLIT, int TILES, int SH, int XMODE, int UNR>
+// WLDS: the wave's weight slab goes HBM -> LDS by DMA (global_load_lds, non-temporal) in 8-row x 128-B pieces -- 8
+// cache lines per wave instruction instead of the 16 of a direct fragment load, which the L1 retires twice as fast
+// -- into a wave-private region (no barrier: the wave waits for its own DMA), swizzled like k_gemm16.hip so that the
+// fragment reads (ds_read_b128, 16 rows x 16 B) are conflict-free.  Needs UNR == K/32/8 (the whole slice at once).
+template <bool SPLIT, int TILES, int SH, int XMODE, int UNR, bool WLDS>
 __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   static_assert(!(SPLIT && XMODE == 2), "the precise mode keeps fp32 activations");
+  static_assert(!WLDS || UNR % 2 == 0, "the LDS image is made of 64-wide k columns");
+  extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];  // WLDS: [wave][tile][UNR/2 columns][16 rows][128 B]
   __shared__ float part[SK_WAVES][TILES][SH][16][17];  // [k-slice][tile][seq half][row][sequence] (+1 pad)
   __shared__ float ssp[SK_WAVES][SH][16];              // XMODE 1: sum(x^2) of each sequence over the wave's K slice
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,10 +102,24 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int h = 0; h < SH; ++h) acc[t][h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  unsigned char* const wbase = wlds + (size_t)wave * (TILES * (UNR / 2) * 2048);
   for (int kb = ks0; kb < ks1; kb += UNR) {
-    uint4 wv[UNR][TILES];
+    uint4 wv[WLDS ? 1 : UNR][TILES];
     float4 x0[UNR][SH], x1[UNR][SH], w0[UNR], w1[UNR];
     uint4 xq[UNR][SH];
+    if (WLDS) {  // the launcher guarantees ks1 - ks0 == UNR here: one pass
+      const int rr = lane >> 3, p = lane & 7;
+#pragma unroll
+      for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int col = 0; col < UNR / 2; ++col)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int r16 = g * 8 + rr, row = n0 + t * 16 + r16;
+            const uint16_t* src = a.W + (size_t)(row < a.N ? row : a.N - 1) * K + (size_t)kb * 32 + col * 64 + (p ^ ((r16 >> 1) & 7)) * 8;
+            __builtin_amdgcn_global_load_lds((sk_gptr_t)src, (sk_lptr_t)(wbase + ((t * (UNR / 2) + col) * 2 + g) * 1024), 16, 0, 2);
+          }
+    }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const bool live = kb + u < ks1;
@@ -103,6 +127,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
       const int ko = ks * 32;  // element offset of this step inside the row
 #pragma unroll
       for (int t = 0; t < TILES; ++t) {
+        if (WLDS) continue;
 #if (Q3A_SK_EXP & 2)
         wv[u][t] = make_uint4(ks, lane, 0u, 0u);
 #else
@@ -130,6 +155,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
         w1[u] = *reinterpret_cast<const float4*>(nrow + ko + 4);
       }
     }
+    if (WLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA is not in the compiler's load bookkeeping
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const bool live = kb + u < ks1;
@@ -150,7 +176,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
         }
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-          const bf16x8_t wf = *reinterpret_cast<const bf16x8_t*>(&wv[u][t]);
+          const bf16x8_t wf = WLDS
+              ? *reinterpret_cast<const bf16x8_t*>(wbase + (t * (UNR / 2) + (u >> 1)) * 2048 + l15 * 128 +
+                                                   ((((u & 1) * 4 + kc) ^ ((l15 >> 1) & 7)) * 16))
+              : *reinterpret_cast<const bf16x8_t*>(&wv[WLDS ? 0 : u][t]);
           acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hi, acc[t][h], 0, 0, 0);
           if (SPLIT) acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, lo, acc[t][h], 0, 0, 0);
         }
@@ -218,17 +247,35 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   }
 }
 
+// dynamic LDS a kernel instance may use: the CU's 160 KiB minus its static arrays (part, ssp) and a 2 KiB margin
+constexpr size_t sk_dyn_lds_max(int tiles, int sh) {
+  return 160 * 1024 - sizeof(float) * (SK_WAVES * tiles * sh * 16 * 17 + SK_WAVES * sh * 16) - 2048;
+}
+
+template <bool SPLIT, int TILES, int SH, int XMODE, int UNR>
+void launch_k(const SkinnyArgs& a, dim3 grid, hipStream_t s) {
+  const dim3 block(SK_WAVES * 64);
+  // weights through LDS when the wave's slice is exactly UNR steps and the image fits next to the reduction buffer
+  const int steps = a.K / 32, per = (steps + SK_WAVES - 1) / SK_WAVES;
+  const size_t wbytes = (size_t)SK_WAVES * TILES * (UNR / 2) * 2048;
+  static const bool wlds_on = [] { const char* e = getenv("Q3A_SKINNY_WLDS"); return !e || atoi(e) != 0; }();  // A/B knob
+  if constexpr (UNR % 2 == 0 && !SPLIT) {
+    if (wlds_on && per == UNR && steps % per == 0 && wbytes <= sk_dyn_lds_max(TILES, SH)) {
+      // dynamic LDS above the 64 KiB default: the attribute is set by skinny_init() (not here: this may run under capture)
+      hipLaunchKernelGGL((skinny_kernel<SPLIT, TILES, SH, XMODE, UNR, true>), grid, block, wbytes, s, a);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((skinny_kernel<SPLIT, TILES, SH, XMODE, UNR, false>), grid, block, 0, s, a);
+}
 template <bool SPLIT, int XMODE, int UNR>
 void launch_u(const SkinnyArgs& a, hipStream_t s) {
-  const dim3 block(SK_WAVES * 64);
   if (a.mode == 2) {
     const dim3 grid((a.N + 31) / 32);
-    if (a.S <= 16) hipLaunchKernelGGL((skinny_kernel<SPLIT, 2, 1, XMODE, UNR>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((skinny_kernel<SPLIT, 2, 2, XMODE, UNR>), grid, block, 0, s, a);
+    if (a.S <= 16) launch_k<SPLIT, 2, 1, XMODE, UNR>(a, grid, s); else launch_k<SPLIT, 2, 2, XMODE, UNR>(a, grid, s);
   } else {
     const dim3 grid((a.N + 15) / 16);
-    if (a.S <= 16) hipLaunchKernelGGL((skinny_kernel<SPLIT, 1, 1, XMODE, UNR>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((skinny_kernel<SPLIT, 1, 2, XMODE, UNR>), grid, block, 0, s, a);
+    if (a.S <= 16) launch_k<SPLIT, 1, 1, XMODE, UNR>(a, grid, s); else launch_k<SPLIT, 1, 2, XMODE, UNR>(a, grid, s);
   }
 }
 template <bool SPLIT, int XMODE>
@@ -242,7 +289,33 @@ void launch_s(const SkinnyArgs& a, hipStream_t s) {
   }
 }
 
+template <int TILES, int SH, int XMODE, int UNR>
+hipError_t allow_big_lds() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_kernel<false, TILES, SH, XMODE, UNR, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sk_dyn_lds_max(TILES, SH));
+}
+template <int XMODE, int UNR>
+hipError_t allow_big_lds_shapes() {
+  hipError_t e = allow_big_lds<1, 1, XMODE, UNR>();
+  if (e == hipSuccess) e = allow_big_lds<1, 2, XMODE, UNR>();
+  if (e == hipSuccess) e = allow_big_lds<2, 1, XMODE, UNR>();
+  if (e == hipSuccess) e = allow_big_lds<2, 2, XMODE, UNR>();
+  return e;
+}
+
 }  // namespace
+
+// Once per device, outside any stream capture: the LDS-staged variants use up to 150 KiB of dynamic LDS.
+const char* skinny_init() {
+  hipError_t e = allow_big_lds_shapes<2, 4>();
+  if (e == hipSuccess) e = allow_big_lds_shapes<2, 8>();
+  if (e == hipSuccess) e = allow_big_lds_shapes<2, 12>();
+  if (e == hipSuccess) e = allow_big_lds_shapes<0, 4>();
+  if (e == hipSuccess) e = allow_big_lds_shapes<0, 6>();
+  if (e == hipSuccess) e = allow_big_lds_shapes<1, 4>();
+  if (e == hipSuccess) e = allow_big_lds_shapes<1, 6>();
+  return e == hipSuccess ? nullptr : "skinny gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+}
 
 const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s) {
   if (a.S <= 0) return nullptr;

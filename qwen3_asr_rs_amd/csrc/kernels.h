@@ -146,6 +146,7 @@ struct SkinnyArgs {
   const float* resid;
 };
 const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s);
+const char* skinny_init();  // once per device before the first launch_skinny (sets the large-LDS kernel attributes)
 // Fragment order of a bf16 activation matrix for up to 32 sequences: the 16 B that lane (sequence s & 15, k-chunk
 // (k >> 3) & 3) of a v_mfma_f32_16x16x32_bf16 B operand needs for k-step k >> 5 and sequence half s >> 4 sit at
 // lane-linear offsets, so one wave load is 1 KiB contiguous (8 cache lines) instead of 16 rows x 64 B (16 lines).

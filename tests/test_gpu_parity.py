@@ -294,6 +294,35 @@ def test_parity_0p6b_dims_30s_clip():
         eng.close()
 
 
+def test_parity_0p6b_dims_batch3_skinny_decode():
+    """0.6B dims, three ragged short clips: the decode step runs on the skinny MFMA GEMM path (RMSNorm fused, bf16
+    fragment-order activations into o/down, weights staged through LDS at K = 1024/2048/3072, lm_head on the LDS-DMA
+    GEMM) -- shapes the tiny checkpoints do not reach.  Teacher-forced against per-utterance oracle runs."""
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
+    clips = [synthetic.synthetic_clip(3, 2.0), synthetic.synthetic_clip(4, 3.1), synthetic.synthetic_clip(5, 1.2)]
+    steps = 3
+    orc = O.AsrOracle(d)
+    refs = [orc.transcribe_ids(c, fixed_new_tokens=steps, last_only=True) for c in clips]
+    for precise in (True, False):
+        eng = HipEngine(d, 0, precise=precise, max_new_tokens=8)
+        eng.mel(clips)
+        eng.encode()
+        logits, nxt = eng.prefill([HipEngine.build_prompt(r.num_audio_tokens) for r in refs])
+        scale = 1 if precise else 2
+        for b in range(3):
+            assert float(np.abs(logits[b] - refs[b].step_logits[0].numpy()).max()) <= TOL[precise]["logit"] * scale
+        for s in range(steps - 1):
+            eng.set_next_tokens([r.all_step_ids[s] for r in refs])
+            lg, nx, _ = eng.decode_step()
+            for b in range(3):
+                err = float(np.abs(lg[b] - refs[b].step_logits[s + 1].numpy()).max())
+                assert err <= TOL[precise]["logit"] * scale, (precise, s, b, err)
+                if precise:
+                    assert int(nx[b]) == refs[b].all_step_ids[s + 1]
+        eng.close()
+    del orc, refs
+
+
 def test_cli_end_to_end(tiny_dir, tmp_path):
     """`asr <model_dir> <wav> [language]` (src/main.rs:7-81): stdout contract and agreement with the library path.
     The model directory gets a synthetic tokenizer.json (id i <-> token "t{i}", two special ids)."""

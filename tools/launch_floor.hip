@@ -191,6 +191,7 @@ int main() {
     uint16_t* xh;
     CHK(hipMalloc(&xf, 32 * 4096 * 4)); CHK(hipMalloc(&yf, 32 * 6144 * 4)); CHK(hipMalloc(&xh, 32 * 4096 * 2)); CHK(hipMalloc(&rmsw, 4096 * 4));
     CHK(hipMemset(xf, 0, 32 * 4096 * 4)); CHK(hipMemset(yf, 0, 32 * 6144 * 4)); CHK(hipMemset(xh, 0, 32 * 4096 * 2)); CHK(hipMemset(rmsw, 0, 4096 * 4));
+    if (const char* e = q3a::skinny_init()) printf("skinny_init: %s\n", e);
     struct Cfg { const char* name; int N, K, mode, xmode; };
     const Cfg cfgs[] = {{"qkv  N=4096 K=1024 fp32 x + fused norm", 4096, 1024, 0, 1}, {"qkv  N=4096 K=1024 fp32 x", 4096, 1024, 0, 0},
                         {"qkv  N=4096 K=1024 bf16 x", 4096, 1024, 0, 2}, {"gateup N=6144 K=1024 GLU fused norm", 6144, 1024, 2, 1},
