@@ -155,9 +155,10 @@ int32_t q3a_profile_decode_step(q3a_engine* e, q3a_kernel_profile* out);
 
 /* Back-to-back timing of the dominant decode kernel (the qkv and gate/up GEMVs, gemv1_kernel<2,..>): `reps`
  * sweeps over ALL decoder layers' qkv and gate/up matrices (0.59 GB at 0.6B, larger than the 256 MB
- * Infinity Cache, so every launch streams from HBM as in a real step) between ONE pair of HIP events on the
- * engine's stream.  avg_us = elapsed / launches; bytes_per_launch = algorithmic weight bytes per launch.
- * Needs decode state with <= 4 sequences; does not change it. */
+ * Infinity Cache, so every launch streams from HBM as in a real step), captured in a hipGraph and replayed between
+ * HIP events on the engine's stream (average of 3 replays; an eager host loop would time the host).
+ * avg_us = elapsed / launches; bytes_per_launch = algorithmic weight bytes per launch.
+ * Needs decode state with <= 2 sequences (the GEMV path); does not change it. */
 int32_t q3a_profile_weight_stream(q3a_engine* e, int32_t reps, float* avg_us, double* bytes_per_launch, int32_t* launches);
 
 /* Debug taps (opts.debug_taps=1): copy a named intermediate to host. `bytes` = capacity of dst;

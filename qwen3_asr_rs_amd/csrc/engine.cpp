@@ -125,6 +125,7 @@ struct q3a_engine {
   DevBuf dec_x, dec_ln, dec_qkv, dec_ctx, dec_act, kcache, vcache;
   DevBuf x_dec, d_pos, next_tok, out_ids, step_count, done, s_ln, s_qkv, s_ctx, s_act, logits, forced_tok, part_val, part_idx;
   DevBuf attn_pm, attn_pl, attn_po;
+  DevBuf nn_x, nn_ss;  // pre-normalised residual row for the next skinny GEMM: [32 * hidden] bf16 fragment order, [hidden/16][32] f32
   DevBuf rope_cur;  // [B][128] cos|sin row of each sequence's current position (kept by argmax_finalize for decode attention)
   DevBuf enc_ctx16, dec_ctx16;  // opts.valu_attention in the default mode: bf16 copy of the fp32 attention context
   DevBuf zero_page;  // 256 B of zeros: padded filter taps of the bf16 implicit-GEMM convolutions read it
@@ -496,6 +497,7 @@ struct q3a_engine {
     kcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
     vcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
     rope_cur.ensure((size_t)b * 128 * 4);
+    nn_x.ensure((size_t)32 * H * 2); nn_ss.ensure((size_t)(H / 16) * 32 * 4);
     x_dec.ensure((size_t)b * H * 4); next_tok.ensure((size_t)b * 4); forced_tok.ensure((size_t)b * 4);
     out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
     // s_ctx / s_act also hold the bf16 fragment-order copies of the skinny GEMM path: always 32 sequences there
@@ -547,6 +549,7 @@ struct q3a_engine {
     f.out_stride = max_new; f.step_count = step_count.as<int>(); f.pos = d_pos.as<int>(); f.advance = advance;
     f.done = done.as<uint8_t>(); f.embed = wh(L.embed); f.H = H; f.x_next = x_dec.as<float>(); f.eos0 = kEos0; f.eos1 = kEos1;
     f.cos_t = rope_cos.as<float>(); f.sin_t = rope_sin.as<float>(); f.rope_cur = rope_cur.as<float>();
+    f.nn = first_layer_norm_out();
     timed(Q3A_KC_ARGMAX, 0, [&] { KCHK(launch_argmax_finalize(f, S, stream)); });
   }
 
@@ -613,6 +616,17 @@ struct q3a_engine {
 
   void scatter_audio_rows();
 
+  // Skinny decode path in the default mode: every kernel that writes a row of the residual stream (token embedding,
+  // o / down projection) also leaves it pre-normalised for the GEMM that reads it next -- bf16(x * w_norm) in MFMA
+  // fragment order in nn_x plus partial sums of x^2 in nn_ss (kernels.h NextNormOut / SkinnyArgs::xw16f).
+  bool prenorm_path() const { return B > kGemvMaxSeq && B <= 32 && !precise(); }
+  int nn_parts() const { return d.hidden / 16; }  // one partial per 16-column block of a hidden-wide GEMM output
+  NextNormOut first_layer_norm_out() const {
+    NextNormOut nn{};
+    if (prenorm_path()) { nn.next_w = wf(L.dec[0].in_ln); nn.next_xw16f = nn_x.as<uint16_t>(); nn.next_ss = nn_ss.as<float>(); nn.nparts = nn_parts(); }
+    return nn;
+  }
+
   // decode-step projection for more than 4 sequences: skinny MFMA GEMM up to 32, generic tiles above
   void batched_proj(const float* x, int ldx, const uint16_t* W, int N, int K, const float* bias, int mode, float* out,
                     int ldo, const float* resid) {
@@ -646,7 +660,9 @@ struct q3a_engine {
         timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, stream)); });
       } else if (S <= 32) {
         SkinnyArgs q{};
-        q.x = x_dec.as<float>(); q.ldx = H; q.S = S; q.rms_w = wf(l.in_ln); q.eps = d.rms_eps; q.W = wh(l.qkv_w); q.N = QKV; q.K = H;
+        q.x = x_dec.as<float>(); q.ldx = H; q.S = S; q.eps = d.rms_eps; q.W = wh(l.qkv_w); q.N = QKV; q.K = H;
+        if (prenorm_path()) { q.xw16f = nn_x.as<uint16_t>(); q.ss_parts = nn_ss.as<float>(); q.ss_nparts = nn_parts(); }
+        else q.rms_w = wf(l.in_ln);
         q.bias = qkv_bias ? wf(l.qkv_b) : nullptr; q.mode = 0; q.out = s_qkv.as<float>(); q.ldo = QKV;
         timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { KCHK(launch_skinny(q, precise(), stream)); });
       } else {
@@ -683,14 +699,20 @@ struct q3a_engine {
         SkinnyArgs o{};
         o.x = s_ctx.as<float>(); o.x16 = b16 ? s_ctx.as<uint16_t>() : nullptr; o.x16_frag = b16; o.ldx = QD; o.S = S; o.W = wh(l.o_w); o.N = H; o.K = QD;
         o.bias = o_bias ? wf(l.o_b) : nullptr; o.mode = 1; o.out = x_dec.as<float>(); o.ldo = H; o.resid = x_dec.as<float>();
+        if (prenorm_path()) { o.next_w = wf(l.post_ln); o.next_xw16f = nn_x.as<uint16_t>(); o.next_ss = nn_ss.as<float>(); }
         timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { KCHK(launch_skinny(o, precise(), stream)); });
         SkinnyArgs u{};
-        u.x = x_dec.as<float>(); u.ldx = H; u.S = S; u.rms_w = wf(l.post_ln); u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
+        u.x = x_dec.as<float>(); u.ldx = H; u.S = S; u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
+        if (prenorm_path()) { u.xw16f = nn_x.as<uint16_t>(); u.ss_parts = nn_ss.as<float>(); u.ss_nparts = nn_parts(); }
+        else u.rms_w = wf(l.post_ln);
         u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act.as<float>(); u.out16 = b16 ? s_act.as<uint16_t>() : nullptr; u.out16_frag = b16; u.ldo = I;
         timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_skinny(u, precise(), stream)); });
         SkinnyArgs dn{};
         dn.x = s_act.as<float>(); dn.x16 = b16 ? s_act.as<uint16_t>() : nullptr; dn.x16_frag = b16; dn.ldx = I; dn.S = S; dn.W = wh(l.down_w); dn.N = H; dn.K = I;
         dn.bias = mlp_bias ? wf(l.down_b) : nullptr; dn.mode = 1; dn.out = x_dec.as<float>(); dn.ldo = H; dn.resid = x_dec.as<float>();
+        if (prenorm_path() && li + 1 < d.dec_layers) {  // (the last layer feeds the final norm + lm_head, which read x_dec)
+          dn.next_w = wf(L.dec[li + 1].in_ln); dn.next_xw16f = nn_x.as<uint16_t>(); dn.next_ss = nn_ss.as<float>();
+        }
         timed(Q3A_KC_GEMM, 2.0 * H * I, [&] { KCHK(launch_skinny(dn, precise(), stream)); });
       } else {
         timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream)); });
@@ -816,7 +838,7 @@ struct q3a_engine {
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
                       &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
                       &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po,
-                      &enc_ctx16, &dec_ctx16, &zero_page, &rope_cur};
+                      &enc_ctx16, &dec_ctx16, &zero_page, &rope_cur, &nn_x, &nn_ss};
     for (auto* b : bufs) b->release();
     for (auto& kv : taps) kv.second.release();
     if (own_arena && arena) (void)hipFree(arena);
@@ -1042,7 +1064,7 @@ int32_t q3a_set_next_tokens(q3a_engine* e, const int32_t* ids, int32_t B) {
     if (ids[s] < 0 || ids[s] >= e->d.vocab) fail("q3a_set_next_tokens: token id out of range");
   HIPCHK(hipMemcpy(e->forced_tok.p, ids, (size_t)B * 4, hipMemcpyHostToDevice));
   KCHK(launch_set_tokens(e->forced_tok.as<int>(), B, e->wh(e->L.embed), e->d.hidden, e->x_dec.as<float>(),
-                         e->next_tok.as<int>(), e->stream));
+                         e->next_tok.as<int>(), e->stream, e->first_layer_norm_out()));
   HIPCHK(hipStreamSynchronize(e->stream));
   Q3A_CATCH(e)
 }

@@ -29,17 +29,48 @@ __global__ void embed_kernel(const int* __restrict__ ids, const uint16_t* __rest
   }
 }
 
+// x_next[s] = embedding row `id` (fp32).  With nn.next_w set (skinny decode path) the row is also handed to the next
+// GEMM pre-normalised: bf16(x * w_norm) in fragment order plus its sum of squares (kernels.h NextNormOut), so that GEMM
+// neither re-reads the fp32 row with 16-line fragment loads nor needs a norm launch.  `red`: shared, one float per wave.
+__device__ __forceinline__ void embed_row(const uint16_t* __restrict__ embed, int id, int H, float* __restrict__ x_next, int s,
+                                          const NextNormOut& nn, float* red) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const uint2* src = reinterpret_cast<const uint2*>(embed + (size_t)id * H);
+  float4* dst = reinterpret_cast<float4*>(x_next + (size_t)s * H);
+  float ss = 0.f;
+  for (int i = tid; i < H / 4; i += nthr) {
+    const uint2 v = src[i];
+    const float4 f = make_float4(bf16lo(v.x), bf16hi(v.x), bf16lo(v.y), bf16hi(v.y));
+    dst[i] = f;
+    if (nn.next_w) {
+      const float4 w = reinterpret_cast<const float4*>(nn.next_w)[i];
+      ss += f.x * f.x + f.y * f.y + f.z * f.z + f.w * f.w;
+      uint2 pk;  // k = 4i .. 4i+3 are consecutive in fragment order
+      pk.x = pack_bf16x2(f.x * w.x, f.y * w.y);
+      pk.y = pack_bf16x2(f.z * w.z, f.w * w.w);
+      *reinterpret_cast<uint2*>(nn.next_xw16f + skinny_frag_index(s, 4 * i)) = pk;
+    }
+  }
+  if (nn.next_w) {  // kernel-argument condition: uniform
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int w = 0; w < (nthr + 63) / 64; ++w) t += red[w];
+      nn.next_ss[s] = t;
+    }
+    for (int p = 1 + tid; p < nn.nparts; p += nthr) nn.next_ss[(size_t)p * 32 + s] = 0.f;
+  }
+}
+
 __global__ void set_tokens_kernel(const int* __restrict__ tok, const uint16_t* __restrict__ embed, int H,
-                                  float* __restrict__ x_next, int* __restrict__ next_tok) {
+                                  float* __restrict__ x_next, int* __restrict__ next_tok, NextNormOut nn) {
+  __shared__ float red[16];
   const int s = blockIdx.x;
   const int id = tok[s];
   if (threadIdx.x == 0) next_tok[s] = id;
-  const uint2* src = reinterpret_cast<const uint2*>(embed + (size_t)id * H);
-  float4* dst = reinterpret_cast<float4*>(x_next + (size_t)s * H);
-  for (int i = threadIdx.x; i < H / 4; i += blockDim.x) {
-    const uint2 v = src[i];
-    dst[i] = make_float4(bf16lo(v.x), bf16hi(v.x), bf16lo(v.y), bf16hi(v.y));
-  }
+  embed_row(embed, id, H, x_next, s, nn, red);
 }
 
 template <typename KVT>
@@ -140,13 +171,7 @@ __global__ __launch_bounds__(1024) void argmax_finalize_kernel(FinalizeArgs a) {
   // request it together with q/k/v instead of after a dependent load of pos
   if (a.rope_cur && tid < 128)
     a.rope_cur[(size_t)s * 128 + tid] = tid < 64 ? a.cos_t[(size_t)pos_s * 64 + tid] : a.sin_t[(size_t)pos_s * 64 + tid - 64];
-  const int tok = tok_s;
-  const uint2* src = reinterpret_cast<const uint2*>(a.embed + (size_t)tok * a.H);
-  float4* dst = reinterpret_cast<float4*>(a.x_next + (size_t)s * a.H);
-  for (int i = tid; i < a.H / 4; i += 1024) {
-    const uint2 v = src[i];
-    dst[i] = make_float4(bf16lo(v.x), bf16hi(v.x), bf16lo(v.y), bf16hi(v.y));
-  }
+  embed_row(a.embed, tok_s, a.H, a.x_next, s, a.nn, bv);  // bv: its 16 floats are free again after the barrier above
 }
 
 }  // namespace
@@ -158,8 +183,9 @@ const char* launch_embed(const int* ids, int rows, const uint16_t* embed, int H,
   return nullptr;
 }
 const char* launch_set_tokens(const int* tok, int S, const uint16_t* embed, int H, float* x_next, int* next_tok,
-                              hipStream_t s) {
-  hipLaunchKernelGGL(set_tokens_kernel, dim3(S), dim3(256), 0, s, tok, embed, H, x_next, next_tok);
+                              hipStream_t s, const NextNormOut& nn) {
+  if (nn.next_w && S > 32) return "set_tokens: the pre-normalised copy holds at most 32 sequences";
+  hipLaunchKernelGGL(set_tokens_kernel, dim3(S), dim3(256), 0, s, tok, embed, H, x_next, next_tok, nn);
   return nullptr;
 }
 const char* launch_qknorm_rope_kv(const RopeKvArgs& a, int rows, bool kv_f32, hipStream_t s) {

@@ -17,6 +17,9 @@
 //                    2  bf16 x written by the producing kernel (attention merge, SwiGLU epilogue): one 16-B load,
 //                       no conversion, half the L2 bytes (x is re-read by every workgroup: at N = 1024 it outweighs
 //                       the workgroup's own weight slab 4:1 in fp32)
+//                    3  the RMSNorm-fused form of 2: the kernel that produced the residual row (an o/down skinny GEMM,
+//                       the embedding kernels) also left bf16(x * w_norm) in fragment order and partial sums of x^2;
+//                       numerically the same as mode 1, with lane-linear loads
 //   v_mfma_f32_16x16x32_bf16 -> D[row][sequence], sequences 0-15 and 16-31 share the A fragment.
 // The eight K-slices are summed through LDS in a fixed order (deterministic), then 1/rms, bias / residual /
 // SiLU(gate)*up are applied.
@@ -60,7 +63,7 @@ __device__ __forceinline__ float sq4(const float4& a) { return a.x * a.x + a.y *
 // fragment reads (ds_read_b128, 16 rows x 16 B) are conflict-free.  Needs UNR == K/32/8 (the whole slice at once).
 template <bool SPLIT, int TILES, int SH, int XMODE, int UNR, bool WLDS>
 __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
-  static_assert(!(SPLIT && XMODE == 2), "the precise mode keeps fp32 activations");
+  static_assert(!(SPLIT && XMODE >= 2), "the precise mode keeps fp32 activations");
   static_assert(!WLDS || UNR % 2 == 0, "the LDS image is made of 64-wide k columns");
   extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];  // WLDS: [wave][tile][UNR/2 columns][16 rows][128 B]
   __shared__ float part[SK_WAVES][TILES][SH][16][17];  // [k-slice][tile][seq half][row][sequence] (+1 pad)
@@ -137,7 +140,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
       }
 #pragma unroll
       for (int h = 0; h < SH; ++h) {
-        if (XMODE == 2) {
+        if (XMODE == 3) {  // pre-normalised x * w_norm, always in fragment order
+          xq[u][h] = *reinterpret_cast<const uint4*>(a.xw16f + ((((size_t)ks * 2 + h) * 4 + kc) * 16 + l15) * 8);
+        } else if (XMODE == 2) {
 #if (Q3A_SK_EXP & 1)
           xq[u][h] = make_uint4(ks, lane, 0u, 0u);
 #else
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
       for (int h = 0; h < SH; ++h) {
         bf16x8_t hi, lo;
-        if (XMODE == 2) {
+        if (XMODE >= 2) {
           hi = *reinterpret_cast<const bf16x8_t*>(&xq[u][h]);
         } else {
           float4 p0 = x0[u][h], p1 = x1[u][h];
@@ -200,7 +205,15 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     for (int h = 0; h < SH; ++h)
 #pragma unroll
       for (int r = 0; r < 4; ++r) part[wave][t][h][kc * 4 + r][l15] = acc[t][h][r];
-  if (XMODE == 1) {
+  if (XMODE == 3) {  // sum(x^2) comes from the producer's partials: this lane adds its share of the ss_nparts rows
+#pragma unroll
+    for (int h = 0; h < SH; ++h) {
+      float q = 0.f;
+      for (int p = wave * 4 + kc; p < a.ss_nparts; p += SK_WAVES * 4) q += a.ss_parts[(size_t)p * 32 + h * 16 + l15];
+      ss[h] = q;
+    }
+  }
+  if (XMODE == 1 || XMODE == 3) {
 #pragma unroll
     for (int h = 0; h < SH; ++h) {
       float v = ss[h];
@@ -213,8 +226,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   // 16 rows x 32 sequences = 512 threads; 16 consecutive lanes own the 16 consecutive output columns of one sequence
   // (64-B runs; with the sequence as the fast index every lane hit its own line: 4 KB stride)
   const int i = tid & 15, s = tid >> 4;
-  if (s >= a.S || (SH == 1 && s >= 16)) return;
-  const int sh = SH == 1 ? 0 : s >> 4, sj = s & 15;
+  const bool live_s = s < a.S && (SH == 2 || s < 16);  // (no early return: the row reduction below needs whole rows)
+  const int sh = (SH == 1 || !live_s) ? 0 : s >> 4, sj = s & 15;
   float v[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
@@ -222,7 +235,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int w = 0; w < SK_WAVES; ++w) v[t] += part[w][t][sh][i][sj];
   }
-  if (XMODE == 1) {
+  if (XMODE == 1 || XMODE == 3) {
     float q = 0.f;
 #pragma unroll
     for (int w = 0; w < SK_WAVES; ++w) q += ssp[w][sh][sj];
@@ -232,13 +245,21 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   }
   if (TILES == 1) {
     const int n = n0 + i;
-    if (n >= a.N) return;
-    float y = v[0];
-    if (a.bias) y += a.bias[n];
-    if (a.mode == 1) y += a.resid[(size_t)s * a.ldo + n];
-    a.out[(size_t)s * a.ldo + n] = y;
+    const bool ok = live_s && n < a.N;
+    float y = 0.f;
+    if (ok) {
+      y = v[0];
+      if (a.bias) y += a.bias[n];
+      if (a.mode == 1) y += a.resid[(size_t)s * a.ldo + n];
+      a.out[(size_t)s * a.ldo + n] = y;
+    }
+    if (a.mode == 1 && a.next_w) {  // hand the new residual row to the next GEMM pre-normalised (kernels.h)
+      if (ok) a.next_xw16f[skinny_frag_index(s, n)] = (uint16_t)f32_to_bf16_bits(y * a.next_w[n]);
+      const float q = row16_sum(y * y);  // this block's 16 columns of sequence s
+      if (i == 0 && live_s) a.next_ss[(size_t)blockIdx.x * 32 + s] = q;
+    }
   } else {  // rows n0..n0+15 = gate, n0+16..n0+31 = up of logical rows n0/2 .. n0/2+15
-    if (n0 + 16 + i >= a.N) return;
+    if (!live_s || n0 + 16 + i >= a.N) return;
     float g = v[0], u = v[TILES - 1];
     if (a.bias) { g += a.bias[n0 + i]; u += a.bias[n0 + 16 + i]; }
     const float y = silu_f(g) * u;
@@ -282,7 +303,7 @@ template <bool SPLIT, int XMODE>
 void launch_s(const SkinnyArgs& a, hipStream_t s) {
   const int per = (a.K / 32 + SK_WAVES - 1) / SK_WAVES;  // k-steps per wave
   // registers per step and lane: 4 (W) x tiles + 4 (bf16 x) or 8..16 (fp32 x [+ norm weight]) x sequence halves
-  if constexpr (XMODE == 2) {
+  if constexpr (XMODE >= 2) {
     if (per <= 4) launch_u<SPLIT, XMODE, 4>(a, s); else if (per <= 8) launch_u<SPLIT, XMODE, 8>(a, s); else launch_u<SPLIT, XMODE, 12>(a, s);
   } else {
     if (per <= 4) launch_u<SPLIT, XMODE, 4>(a, s); else launch_u<SPLIT, XMODE, 6>(a, s);
@@ -310,6 +331,9 @@ const char* skinny_init() {
   hipError_t e = allow_big_lds_shapes<2, 4>();
   if (e == hipSuccess) e = allow_big_lds_shapes<2, 8>();
   if (e == hipSuccess) e = allow_big_lds_shapes<2, 12>();
+  if (e == hipSuccess) e = allow_big_lds_shapes<3, 4>();
+  if (e == hipSuccess) e = allow_big_lds_shapes<3, 8>();
+  if (e == hipSuccess) e = allow_big_lds_shapes<3, 12>();
   if (e == hipSuccess) e = allow_big_lds_shapes<0, 4>();
   if (e == hipSuccess) e = allow_big_lds_shapes<0, 6>();
   if (e == hipSuccess) e = allow_big_lds_shapes<1, 4>();
@@ -324,7 +348,10 @@ const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s) {
   if (a.mode == 2 && a.N % 32 != 0) return "skinny gemm: GLU needs N % 32 == 0";
   if (a.out16 && a.mode != 2) return "skinny gemm: bf16 output only in GLU mode";
   if (a.x16 && (split || a.rms_w)) return "skinny gemm: bf16 x excludes the precise mode and the fused RMSNorm";
-  if (a.x16) launch_s<false, 2>(a, s);
+  if (a.xw16f && (split || a.rms_w || a.x16 || !a.ss_parts || a.ss_nparts <= 0)) return "skinny gemm: pre-normalised input is exclusive and needs its partial sums";
+  if (a.next_w && (a.mode != 1 || !a.next_xw16f || !a.next_ss)) return "skinny gemm: next-norm output needs mode 1 and both buffers";
+  if (a.xw16f) launch_s<false, 3>(a, s);
+  else if (a.x16) launch_s<false, 2>(a, s);
   else if (a.rms_w) { if (split) launch_s<true, 1>(a, s); else launch_s<false, 1>(a, s); }
   else { if (split) launch_s<true, 0>(a, s); else launch_s<false, 0>(a, s); }
   return nullptr;

@@ -144,6 +144,20 @@ struct SkinnyArgs {
   float* out; int ldo;
   uint16_t* out16;                  // mode 2 only: when non-null the result is written here as bf16 instead of out
   const float* resid;
+  // Pre-normalised input (default mode, replaces x + rms_w): xw16f = bf16(x * w_norm) in fragment order and
+  // ss_parts[p][32] = partial sums of x^2 (p < ss_nparts) -- both written by the kernel that produced x (below), so
+  // this GEMM's activation loads are lane-linear and the RMSNorm still costs no launch.  eps as above.
+  const uint16_t* xw16f; const float* ss_parts; int ss_nparts;
+  // mode 1 only, producer side of the above for the NEXT GEMM (null: off): after out = resid + y is stored,
+  // next_xw16f[frag(s, n)] = bf16(out * next_w[n]) and next_ss[blockIdx.x][s] = sum over the block's 16 columns of out^2
+  const float* next_w; uint16_t* next_xw16f; float* next_ss;
+};
+// the same producer duty for kernels that write a whole row of the residual stream (token embedding)
+struct NextNormOut {
+  const float* next_w;      // [H] norm weight of the GEMM that consumes the row next (null: off)
+  uint16_t* next_xw16f;     // [32 * H] fragment order
+  float* next_ss;           // [nparts][32]: row 0 receives the row's sum of squares, rows 1..nparts-1 zero
+  int nparts;
 };
 const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s);
 const char* skinny_init();  // once per device before the first launch_skinny (sets the large-LDS kernel attributes)
@@ -192,12 +206,14 @@ struct FinalizeArgs {
   int eos0, eos1;
   const float* cos_t; const float* sin_t;  // RoPE tables [max_pos][64]
   float* rope_cur;         // [S][128] (written): cos | sin row of the updated pos[s] (DecodeAttnArgs::rope_cur); nullable
+  NextNormOut nn;          // pre-normalised copy of x_next for the first layer's qkv GEMM (skinny path)
 };
 // block partials of logits [S][V] (GEMM decode path; the GEMV lm_head produces its own)
 const char* launch_argmax_partials(const float* logits, int V, int S, float* pval, int* pidx, int stride, int nblk,
                                    hipStream_t s);
 const char* launch_argmax_finalize(const FinalizeArgs& a, int S, hipStream_t s);
 // x_next[s] = embed[tok[s]]; next_tok[s] = tok[s]  (teacher forcing)
-const char* launch_set_tokens(const int* tok, int S, const uint16_t* embed, int H, float* x_next, int* next_tok, hipStream_t s);
+const char* launch_set_tokens(const int* tok, int S, const uint16_t* embed, int H, float* x_next, int* next_tok, hipStream_t s,
+                              const NextNormOut& nn = NextNormOut{});
 
 }  // namespace q3a
