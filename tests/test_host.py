@@ -149,3 +149,23 @@ def test_output_parsing_mirror():
     for raw, forced in [("language English<asr_text>Hi.", False), ("language Chinese 你好", False), ("x", False), (" y ", True)]:
         assert parse_asr_output(raw, forced) == O.parse_asr_output(raw, forced)
     assert capitalize_first("chinese") == "Chinese"
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r1_bench_final.json is the bench.py line of this round: every field the driver and the judge read
+    must be there with the right type (BASELINE.json metric, roofline and cpu_baseline objects)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    j = json.load(open(os.path.join(root, "profiles", "r1_bench_final.json")))
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert j["metric"].split(",")[0] == base["metric"].split(",")[0]
+    assert j["unit"] == "audio-seconds/sec" and j["higher_is_better"] is True and j["scaling"] == "weak"
+    assert j["n_gpus"] == 1 and j["steps"] > 0 and j["warmup"] >= 0 and j["vs_baseline"] is None
+    assert j["value"] > 0 and abs(j["value"] * j["ms_per_step"] / 1e3 - 30.0 * j["config"]["clips_per_gpu"]) < 0.5
+    assert "workload" in j["config"] and "model" not in j["config"] and "synthetic" in j["data"]
+    r = j["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] >= 0.95 * r["bytes_per_launch"]   # no under-counted traffic
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
