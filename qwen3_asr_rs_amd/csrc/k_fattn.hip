@@ -113,7 +113,6 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
       const int c = tid + i * 256, row = c / CPR, d0 = (c % CPR) * 8;
       *reinterpret_cast<uint4*>(&k_lds[row * K_STRIDE + d0]) = kreg[i];
       const uint32_t w[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
-#pragma unroll
       // transpose: V^T[d][key].  The 16 lanes that share a key write dims d0 = 0, 8, .., 120: rows 640 B apart, i.e.
       // two banks for all of them (measured: LDS bank-conflict rate 0.81, 27 % of the wave cycles waiting on LDS).
       // The 4-key groups of row d are therefore stored at group index (g ^ ((d >> 3) & 7)) -- the reads below apply
