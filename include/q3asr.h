@@ -191,6 +191,11 @@ int32_t q3a_parse_asr_output(const char* raw, int32_t language_forced, char* lan
                              int32_t text_cap);
 int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
 
+/* A/B knobs for kernel experiments (process-wide; not part of the reference interface).  Keys:
+ *   "gemm256_min_tiles"  minimum number of 256x256 output tiles for which the bf16 GEMM dispatches to the 8-wave
+ *                        counted-vmcnt kernel (k_gemm256.hip): 0 = whenever the shape allows, a huge value = never. */
+int32_t q3a_debug_set(const char* key, int32_t value);
+
 /* Kernel self-tests against naive device references (no model needed): returns max abs error. */
 int32_t q3a_selftest_gemm(int32_t device, int32_t M, int32_t N, int32_t K, int32_t split, float* max_abs_err,
                           float* ref_abs_max);

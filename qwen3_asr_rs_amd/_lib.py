@@ -15,7 +15,7 @@ SYMBOLS = [
     "q3a_engine_destroy", "q3a_last_error", "q3a_get_dims", "q3a_num_frames", "q3a_num_audio_tokens",
     "q3a_build_prompt", "q3a_mel", "q3a_encode", "q3a_prefill", "q3a_decode_step", "q3a_set_next_tokens",
     "q3a_upload_pcm", "q3a_run_resident", "q3a_fetch_ids", "q3a_transcribe_batch", "q3a_stage_timings",
-    "q3a_profile_decode_step", "q3a_profile_weight_stream", "q3a_debug_read", "q3a_selftest_gemm", "q3a_selftest_gemm16",
+    "q3a_profile_decode_step", "q3a_profile_weight_stream", "q3a_debug_read", "q3a_debug_set", "q3a_selftest_gemm", "q3a_selftest_gemm16",
     "q3a_load_audio", "q3a_resample", "q3a_free", "q3a_tokenizer_create", "q3a_tokenizer_destroy",
     "q3a_tokenizer_decode", "q3a_tokenizer_encode", "q3a_parse_asr_output", "q3a_capitalize_first",
 ]
@@ -86,6 +86,7 @@ def load() -> C.CDLL:
         "q3a_profile_decode_step": (i32, [P, C.POINTER(KernelProfile)]),
         "q3a_profile_weight_stream": (i32, [P, i32, f32p, C.POINTER(C.c_double), i32p]),
         "q3a_debug_read": (i32, [P, C.c_char_p, P, u64, C.POINTER(u64)]),
+        "q3a_debug_set": (i32, [C.c_char_p, i32]),
         "q3a_selftest_gemm": (i32, [i32, i32, i32, i32, i32, f32p, f32p]),
         "q3a_selftest_gemm16": (i32, [i32, i32, i32, i32, i32, f32p, f32p, f32p, f32p]),
         "q3a_load_audio": (i32, [C.c_char_p, i32, C.POINTER(f32p), i64p]),

@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libq3asr_hip.so")
 BIN_DIR = os.path.join(HERE, "bin")
 CLI_PATH = os.path.join(BIN_DIR, "asr")  # the reference's CLI (src/main.rs) on top of the C ABI
 
-SOURCES = ["engine.cpp", "model.cpp", "k_gemm.hip", "k_mel.hip", "k_conv1.hip", "k_norm.hip", "k_attn.hip", "k_decode.hip", "k_gemv.hip", "k_dattn.hip", "k_fattn.hip", "k_skinny.hip", "k_gemm16.hip",
+SOURCES = ["engine.cpp", "model.cpp", "k_gemm.hip", "k_mel.hip", "k_conv1.hip", "k_norm.hip", "k_attn.hip", "k_decode.hip", "k_gemv.hip", "k_dattn.hip", "k_fattn.hip", "k_skinny.hip", "k_gemm16.hip", "k_gemm256.hip",
            "host_audio.cpp", "host_text.cpp", "host_abi.cpp"]
 HEADERS = ["dev.h", "kernels.h", "model.h", "json.h", "host.h", os.path.join("..", "..", "include", "q3asr.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -256,8 +256,12 @@ struct q3a_engine {
   // =====================================================================================
   // batch geometry (host integers; audio_encoder.rs:79-121, 263-279)
   void set_batch(const int64_t* ns, int b) {
+    // a failure below must not leave the previous batch's device tables paired with new host geometry
+    have_mel = have_enc = have_prefill = false;
+    B = 0;
     if (b <= 0) fail("batch must be >= 1");
-    B = b;
+    for (int u = 0; u < b; ++u)
+      if (ns[u] < 161) fail("utterance too short: reflection padding needs more than 160 samples (src/mel.rs:63-65)");
     n_samples.assign(ns, ns + b);
     pcm_off.resize(b); mel_off.resize(b); n_frames.resize(b); n_chunks.resize(b); T.resize(b); tok_off.resize(b);
     std::vector<int> chunk_utt, chunk_frame0, convout_map, conv3_map;
@@ -267,7 +271,6 @@ struct q3a_engine {
     total_chunks = 0; max_frames = 0; enc_max_seg = 0;
     const int cf = d.chunk_frames(), tpc = d.tokens_per_chunk(), cpw = d.chunks_per_window();
     for (int u = 0; u < b; ++u) {
-      if (ns[u] < 161) fail("utterance too short: reflection padding needs more than 160 samples (src/mel.rs:63-65)");
       pcm_off[u] = po;
       po += (ns[u] + 3) & ~int64_t(3);
       int F = (int)((ns[u] + 159) / 160);  // mel.rs:51,83-84
@@ -323,7 +326,7 @@ struct q3a_engine {
     mel.ensure((size_t)mo * 4);
     gmax.ensure((size_t)b * 4);
     HIPCHK(hipStreamSynchronize(stream));  // host vectors above go out of scope
-    have_mel = have_enc = have_prefill = false;
+    B = b;  // committed only after every table is on the device
   }
 
   void upload_pcm(const float* host, const int64_t* ns, int b) {
@@ -476,7 +479,7 @@ struct q3a_engine {
     total_P = off;
     max_new = std::min(std::max(max_new_req, 1), opts.max_new_tokens);
     max_ctx = ((maxP + max_new + 1 + 63) / 64) * 64;
-    ensure_rope(max_ctx);
+    ensure_rope(max_ctx + 1);  // argmax_finalize reads the row of the position AFTER the last one the cache can hold
     std::vector<int> ids_v(ids_h, ids_h + total_P);
     std::vector<AttnSeg> segs(b);
     for (int s = 0; s < b; ++s)
@@ -1213,6 +1216,13 @@ int32_t q3a_debug_read(q3a_engine* e, const char* name, void* dst, uint64_t byte
     HIPCHK(hipMemcpy(dst, it->second.p, n, hipMemcpyDeviceToHost));
   }
   Q3A_CATCH(e)
+}
+
+int32_t q3a_debug_set(const char* key, int32_t value) {
+  if (!key) return 1;
+  if (strcmp(key, "gemm256_min_tiles") == 0) { g_gemm256_min_tiles = value; return 0; }
+  g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";
+  return 1;
 }
 
 int32_t q3a_selftest_gemm(int32_t device, int32_t M, int32_t N, int32_t K, int32_t split, float* max_abs_err,

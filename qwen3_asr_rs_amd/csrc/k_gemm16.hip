@@ -387,6 +387,7 @@ const char* launch_gemm16(const uint16_t* X, int lda, const uint16_t* W, int M, 
   if (M <= 0) return nullptr;
   if (K % 32 != 0 || lda % 8 != 0) return "gemm16: K must be a multiple of 32 and lda of 8";
   if (glu && N % 32 != 0) return "gemm16: GLU needs N % 32 == 0";
+  if (K % 64 == 0 && gemm256_eligible(M, N, K)) return launch_gemm256(X, lda, W, M, N, K, ep, glu, s);
   DenseA16 A{X, lda};
   // few tiles and a long K: 32x32 tiles whose 4 waves split K (A/B knob: Q3A_GEMM16_KSPLIT=0 disables)
   static const bool ksplit_on = [] { const char* e = getenv("Q3A_GEMM16_KSPLIT"); return !e || atoi(e) != 0; }();
@@ -420,6 +421,7 @@ const char* launch_conv3x3s2_gemm16(const uint16_t* X, const uint16_t* zero_page
   ConvA16 A{X, zero_page, H, Wd, C, (H - 1) / 2 + 1, (Wd - 1) / 2 + 1};
   const int M = imgs * A.OH * A.OW;
   if (M <= 0) return nullptr;
+  if (gemm256_eligible(M, Cout, 9 * C)) return launch_conv3x3s2_gemm256(X, zero_page, imgs, H, Wd, C, Wt, Cout, ep, s);
   // a K tile must not straddle two filter taps: BK has to divide C
   if (C % 64 == 0) launch_sized16<64, false>(A, Wt, M, Cout, 9 * C, ep, s);
   else launch_sized16<32, false>(A, Wt, M, Cout, 9 * C, ep, s);

@@ -1,0 +1,368 @@
+// 256 x 256 x 64 bf16 MFMA GEMM for gfx950, 8 waves, LDS-DMA staging with counted vmcnt across raw barriers.
+//
+//   Y[M][N] = act( X[M][K] . W[N][K]^T + bias ) (+ residual)      X, W bf16 (K contiguous), fp32 accumulate
+//
+// Same contract / epilogues as k_gemm16.hip (GemmEpilogue); this is the kernel for the batch-sized problems of the
+// encoder and the prefill (M = 12 480 ... 768 000 rows at 32 clips), where the 128 x 128, 4-wave, one-barrier-per-K-tile
+// kernel of k_gemm16.hip parks its waves 2/3 of the time at that barrier (profiles/r1_sq_breakdown.txt).
+//
+// Structure (cdna_hip_programming.md "256^2 8-phase template", re-derived here because its source is not in the image):
+//   * workgroup = 8 waves = 2 (M) x 4 (N); a wave owns a 128 x 64 output tile = 8 x 4 fragments of
+//     v_mfma_f32_16x16x32_bf16 (128 accumulator registers);
+//   * LDS = 2 K-tile buffers x (A 256 x 64 + B 256 x 64) bf16 = 128 KiB, ONE __shared__ array.  A buffer is made of 1 KiB
+//     subtiles of 16 rows x 32 k: exactly what ONE global_load_lds wave instruction writes and what ONE ds_read_b128
+//     fragment read consumes.  Inside a subtile the 16-B chunk c of row r sits at chunk position c ^ ((r >> 3) << 1)
+//     (the guide's st_16x32 swizzle: byte ^= ((byte >> 9) & 1) << 5); the LDS-DMA image is lane-linear, so the
+//     permutation is applied to the SOURCE address and again to the read address: conflict-free ds_read_b128;
+//   * a K tile is consumed in 4 phases of 16 MFMAs per wave (one 64 x 32 quadrant of the wave tile x K = 64):
+//         P1  read A rows m0 (8 reads) + B rows n0 (4)     MFMA m0 x n0
+//         P2  read B rows n1 (4)                            MFMA m0 x n1
+//         P3  read A rows m1 (8)                            MFMA m1 x n1
+//         P4  (B n0 still in registers)                     MFMA m1 x n0
+//     every phase = { fragment reads + ONE 16 KiB staging unit (2 LDS-DMA instructions per wave) ; s_barrier ;
+//     lgkmcnt(0) ; s_setprio 1 ; 16 MFMA ; s_setprio 0 ; s_barrier }.  The two wave groups (wr = 0 / 1, one wave of each
+//     on every SIMD) run ONE barrier apart, so one group's MFMA segment overlaps the other's read/stage segment;
+//   * staging units are the row sets that are freed together: A-m0 / B-n0 (last read in P1), B-n1 (P2), A-m1 (P3).  A unit
+//     is re-staged >= 2 phases after its last read (WAR, the groups being one barrier apart) and waited for with a
+//     COUNTED vmcnt one phase before it is read (RAW: wait -> barrier -> read):
+//         P1(t) stages B-n1(t+1)   P2(t) stages A-m1(t+1)   P3(t) stages A-m0(t+2)   P4(t) stages B-n0(t+2)
+//     so four units (8 DMA instructions per wave, 64 KiB per CU) are always in flight and nothing but the last tile ever
+//     waits with vmcnt(0).  The barriers are raw s_barrier (a __syncthreads() would drain the DMA queue).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "dev.h"
+#include "kernels.h"
+
+namespace q3a {
+namespace {
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+constexpr int G_BM = 256, G_BN = 256, G_BK = 64;
+constexpr int G_BUF = 65536;    // bytes per K-tile buffer: A 32 KiB then B 32 KiB
+constexpr int G_BOFF = 32768;   // B region inside a buffer
+
+// ---- A-operand views --------------------------------------------------------------------------------------------
+// Row state is per lane: the lane stages 16 B of ONE row per LDS-DMA instruction.  src(k) returns the address of the
+// 8 bf16 at column k (k = tile k0 + half * 32; the lane's swizzled chunk offset is folded into the row state).
+struct DenseA256 {
+  const uint16_t* x;
+  int lda;
+  struct Row { const uint16_t* p; };
+  __device__ __forceinline__ Row init(int m, int M, int chunk_elems) const {
+    if (m >= M) m = M - 1;  // tail rows are clamped: their products are never stored
+    return Row{x + (size_t)m * lda + chunk_elems};
+  }
+  typedef int KIter;  // column of the 32-wide half row being staged (wave-uniform)
+  __device__ __forceinline__ KIter kbegin() const { return 0; }
+  __device__ __forceinline__ void knext(KIter& k) const { k += 32; }
+  __device__ __forceinline__ const uint16_t* src(const Row& r, const KIter& k) const { return r.p + k; }
+};
+
+// im2col view of an NHWC bf16 feature map [img][H][W][C] for a 3x3 stride-2 pad-1 convolution; K = 9 * C ordered
+// (kh, kw, c).  C % 32 == 0, so a 32-wide half row of a K tile never straddles two filter taps.
+struct ConvA256 {
+  const uint16_t* x;
+  const uint16_t* zero;  // >= 64 B of zeros for padded taps
+  int H, W, C, OH, OW;
+  struct Row { int img, ih0, iw0, chunk; };
+  __device__ __forceinline__ Row init(int m, int M, int chunk_elems) const {
+    if (m >= M) m = M - 1;
+    const int img = m / (OH * OW);
+    const int r = m - img * OH * OW;
+    const int oh = r / OW, ow = r - oh * OW;
+    return Row{img, oh * 2 - 1, ow * 2 - 1, chunk_elems};
+  }
+  struct KIter { int kh, kw, c0; };  // filter tap and first channel of the 32-wide half row (wave-uniform: scalar registers)
+  __device__ __forceinline__ KIter kbegin() const { return KIter{0, 0, 0}; }
+  __device__ __forceinline__ void knext(KIter& k) const {
+    k.c0 += 32;
+    if (k.c0 >= C) { k.c0 = 0; if (++k.kw == 3) { k.kw = 0; ++k.kh; } }
+  }
+  __device__ __forceinline__ const uint16_t* src(const Row& r, const KIter& k) const {
+    const int ih = r.ih0 + k.kh, iw = r.iw0 + k.kw;
+    const bool ok = k.kh < 3 && ih >= 0 && ih < H && iw >= 0 && iw < W;  // kh == 3: the zero half tile past K = 9 * C
+    const uint16_t* p = x + (((size_t)r.img * H + ih) * W + iw) * C + k.c0 + r.chunk;
+    return ok ? p : zero + r.chunk;
+  }
+};
+
+#define Q3A_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define Q3A_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define Q3A_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+  static_assert(N == 0 || N == 2 || N == 4 || N == 8, "vmcnt value");
+  if constexpr (N == 0) Q3A_WAIT_VM(0);
+  else if constexpr (N == 2) Q3A_WAIT_VM(2);
+  else if constexpr (N == 4) Q3A_WAIT_VM(4);
+  else Q3A_WAIT_VM(8);
+}
+
+template <bool GLU, class ALoader>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16_t* __restrict__ Wt,
+                                                         const uint16_t* __restrict__ zero, int M, int N, int K, GemmEpilogue ep) {
+  __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * G_BUF];  // the ONLY LDS object of this kernel
+
+  const int tiles_m = (M + G_BM - 1) / G_BM, tiles_n = (N + G_BN - 1) / G_BN;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {  // bijective XCD remap: consecutive tile ids stay on one XCD / L2
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  // N fastest: the N tiles that share an A panel (the big operand when M >> N) run next to each other
+  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  const int m0 = tm * G_BM, n0 = tn * G_BN;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- staging assignment: per unit a wave fills the two 1 KiB subtiles (k halves) of ONE 16-row block ----
+  const int srow = lane >> 2;                                 // row inside the 16-row block
+  const int schunk = ((lane & 3) ^ (((lane >> 5) & 1) << 1)) * 8;  // swizzled source chunk (elements) inside the 32-wide half row
+  const int rbA0 = wave + (wave >= 4 ? 4 : 0), rbA1 = rbA0 + 4;    // A-m0: row blocks {0-3, 8-11}; A-m1: {4-7, 12-15}
+  const int rbB0 = (wave >> 1) * 4 + (wave & 1), rbB1 = rbB0 + 2;  // B-n0: {0,1,4,5,..}; B-n1: {2,3,6,7,..}
+  const typename ALoader::Row rowA0 = A.init(m0 + rbA0 * 16 + srow, M, schunk);
+  const typename ALoader::Row rowA1 = A.init(m0 + rbA1 * 16 + srow, M, schunk);
+  const uint16_t* rowB0;
+  const uint16_t* rowB1;
+  {
+    const int nb0 = n0 + rbB0 * 16 + srow, nb1 = n0 + rbB1 * 16 + srow;
+    rowB0 = Wt + (size_t)(nb0 < N ? nb0 : N - 1) * K + schunk;
+    rowB1 = Wt + (size_t)(nb1 < N ? nb1 : N - 1) * K + schunk;
+  }
+  const int dA0 = rbA0 * 2048, dA1 = rbA1 * 2048, dB0 = G_BOFF + rbB0 * 2048, dB1 = G_BOFF + rbB1 * 2048;  // wave-uniform
+
+  typedef typename ALoader::KIter KIter;
+  auto stage_a = [&](const typename ALoader::Row& r, const KIter& ka, const KIter& kb, int dst) {  // ka / kb: the two k halves
+    __builtin_amdgcn_global_load_lds((gptr_t)A.src(r, ka), (lptr_t)(lds + dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)A.src(r, kb), (lptr_t)(lds + dst + 1024), 16, 0, 0);
+  };
+  // K % 64 == 32 (the convolutions: K = 9 * 480): the second half of the last tile is read from the zero page on both sides
+  auto stage_b = [&](const uint16_t* r, int k0, int dst) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(r + k0), (lptr_t)(lds + dst), 16, 0, 0);
+    const uint16_t* h1 = k0 + 32 < K ? r + k0 + 32 : zero + schunk;  // wave-uniform condition
+    __builtin_amdgcn_global_load_lds((gptr_t)h1, (lptr_t)(lds + dst + 1024), 16, 0, 0);
+  };
+
+  // ---- fragment read addresses: lane reads row (lane & 15), logical chunk (lane >> 4) of a subtile ----
+  const int roff = (lane & 15) * 64 + (((lane >> 4) ^ (((lane & 15) >> 3) << 1)) * 16);
+  const int ra_base = wr * 16384 + roff;            // A subtile (i, ks) of this wave: + (i * 2 + ks) * 1024
+  const int rb_base = G_BOFF + wc * 8192 + roff;    // B subtile (j, ks):              + (j * 2 + ks) * 1024
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int KT = (K + G_BK - 1) / G_BK;  // >= 2 (launcher)
+
+  // ---- prologue: tile 0 complete + the two early units of tile 1 ----
+  KIter kit = A.kbegin();  // A-operand column iterator; after the prologue: column (t + 1) * 64 at the start of tile t
+  {
+    const KIter k00 = kit;
+    A.knext(kit);
+    const KIter k01 = kit;
+    A.knext(kit);  // column 64
+    KIter k11 = kit;
+    A.knext(k11);
+    stage_a(rowA0, k00, k01, dA0);
+    stage_b(rowB0, 0, dB0);
+    stage_b(rowB1, 0, dB1);
+    stage_a(rowA1, k00, k01, dA1);
+    stage_a(rowA0, kit, k11, G_BUF + dA0);
+    stage_b(rowB0, G_BK, G_BUF + dB0);
+  }
+  Q3A_WAIT_VM(8);  // A-m0(0), B-n0(0) have landed (this wave's part)
+  Q3A_BARRIER();
+  if (wr == 1) Q3A_BARRIER();  // the second wave group runs one barrier behind the first
+
+  bf16x8_t af[8], b0f[4], b1f[4];
+
+  // one K tile.  N1: tile t+1 exists, N2: tile t+2 exists (compile time -> exact vmcnt values)
+  auto tile = [&](int t, auto n1_tag, auto n2_tag) {
+    constexpr bool N1 = decltype(n1_tag)::value, N2 = decltype(n2_tag)::value;
+    const int cb = (t & 1) * G_BUF, nb = G_BUF - cb;  // this tile's buffer / the other one (wave-uniform)
+    const int k1 = (t + 1) * G_BK, k2 = (t + 2) * G_BK;
+    const KIter ka1 = kit;  // columns k1, k1 + 32, k2, k2 + 32 of the A operand
+    A.knext(kit);
+    const KIter kb1 = kit;
+    A.knext(kit);           // = column k2: where the next tile starts
+    const KIter ka2 = kit;
+    KIter kb2 = kit;
+    A.knext(kb2);
+    const bf16x8_t* ap = reinterpret_cast<const bf16x8_t*>(lds + cb + ra_base);
+    const bf16x8_t* bp = reinterpret_cast<const bf16x8_t*>(lds + cb + rb_base);
+    // ---------------- P1 ----------------
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b0f[q] = bp[q * 64];          // B n0: j = 0,1 x ks = 0,1  (subtile index j*2+ks = q)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) af[q] = ap[q * 64];           // A m0: i = 0..3 x ks
+    if constexpr (N1) stage_b(rowB1, k1, nb + dB1);
+    wait_vm<N1 ? 8 : 2>();                                    // B-n1(t) has landed
+    __builtin_amdgcn_sched_barrier(0);
+    Q3A_BARRIER();
+    Q3A_WAIT_LGKM0();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i * 2 + ks], b0f[j * 2 + ks], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    Q3A_BARRIER();
+    // ---------------- P2 ----------------
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b1f[q] = bp[(4 + q) * 64];    // B n1: j = 2,3
+    if constexpr (N1) stage_a(rowA1, ka1, kb1, nb + dA1);
+    wait_vm<N1 ? 8 : 0>();                                    // A-m1(t) has landed
+    __builtin_amdgcn_sched_barrier(0);
+    Q3A_BARRIER();
+    Q3A_WAIT_LGKM0();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i * 2 + ks], b1f[j * 2 + ks], acc[i][2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    Q3A_BARRIER();
+    // ---------------- P3 ----------------
+#pragma unroll
+    for (int q = 0; q < 8; ++q) af[q] = ap[(8 + q) * 64];     // A m1: i = 4..7
+    if constexpr (N2) stage_a(rowA0, ka2, kb2, cb + dA0);           // A-m0 / B-n0 of this buffer were last read in P1
+    __builtin_amdgcn_sched_barrier(0);
+    Q3A_BARRIER();
+    Q3A_WAIT_LGKM0();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i * 2 + ks], b1f[j * 2 + ks], acc[4 + i][2 + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    Q3A_BARRIER();
+    // ---------------- P4 ----------------
+    if constexpr (N2) stage_b(rowB0, k2, cb + dB0);
+    if constexpr (N1) wait_vm<N2 ? 8 : 4>();                  // A-m0(t+1), B-n0(t+1) have landed
+    __builtin_amdgcn_sched_barrier(0);
+    Q3A_BARRIER();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i * 2 + ks], b0f[j * 2 + ks], acc[4 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    Q3A_BARRIER();
+  };
+  {
+    int t = 0;
+    for (; t + 2 < KT; ++t) tile(t, std::true_type{}, std::true_type{});
+    tile(t, std::true_type{}, std::false_type{});
+    tile(t + 1, std::false_type{}, std::false_type{});
+  }
+  if (wr == 0) Q3A_BARRIER();  // balance the extra barrier of the second group
+
+  // ---- epilogue (C/D layout of v_mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg) ----
+  const int col_in = lane & 15, row_in = (lane >> 4) * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wr * 128 + i * 16 + row_in + r;
+      if (m >= M) continue;
+      const int orow = ep.rowmap ? ep.rowmap[m] : m;
+      if (orow < 0) continue;
+      if (!GLU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + wc * 64 + j * 16 + col_in;
+          if (n >= N) continue;
+          float v = acc[i][j][r];
+          if (ep.bias) v += ep.bias[n];
+          if (ep.addend) v += ep.addend[(size_t)(m % ep.addend_period) * ep.ldo + n];
+          if (ep.act == 1) v = gelu_fast(v);  // default mode: the result is rounded to bf16 (dev.h)
+          if (ep.resid) v += ep.resid[(size_t)orow * ep.ldo + n];
+          if (ep.out16) ep.out16[(size_t)orow * ep.ldo + n] = (uint16_t)f32_to_bf16_bits(v);
+          else ep.out[(size_t)orow * ep.ldo + n] = v;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j + 1 < 4; j += 2) {
+          const int nb = n0 + wc * 64 + j * 16;
+          if (nb + 16 + col_in >= N) continue;
+          float g = acc[i][j][r], u = acc[i][j + 1][r];
+          if (ep.bias) { g += ep.bias[nb + col_in]; u += ep.bias[nb + 16 + col_in]; }
+          const float v = silu_fast(g) * u;
+          if (ep.out16) ep.out16[(size_t)orow * ep.ldo + (nb >> 1) + col_in] = (uint16_t)f32_to_bf16_bits(v);
+          else ep.out[(size_t)orow * ep.ldo + (nb >> 1) + col_in] = v;
+        }
+      }
+    }
+  }
+}
+
+template <bool GLU, class ALoader>
+void launch256(const ALoader& A, const uint16_t* W, const uint16_t* zero, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s) {
+  const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
+  hipLaunchKernelGGL((gemm256_kernel<GLU, ALoader>), dim3(tiles), dim3(512), 0, s, A, W, zero, M, N, K, ep);
+}
+
+}  // namespace
+
+// A/B knob: minimum number of 256 x 256 tiles for the dispatch to this kernel (0 = whenever the shape allows, huge = never);
+// environment Q3A_GEMM256_MIN_TILES at first use, q3a_debug_set("gemm256_min_tiles", v) afterwards
+int g_gemm256_min_tiles = -1;
+bool gemm256_eligible(int M, int N, int K) {
+  if (g_gemm256_min_tiles < 0) {
+    const char* e = getenv("Q3A_GEMM256_MIN_TILES");
+    g_gemm256_min_tiles = e ? atoi(e) : 128;
+  }
+  if (K % 32 != 0 || K < 2 * G_BK) return false;
+  const long tiles = (long)((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
+  return tiles >= g_gemm256_min_tiles;
+}
+
+const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
+                           bool glu, hipStream_t s) {
+  if (M <= 0) return nullptr;
+  if (K % G_BK != 0 || K < 2 * G_BK || lda % 8 != 0) return "gemm256: K must be a multiple of 64 (>= 128) and lda of 8";
+  if (glu && N % 32 != 0) return "gemm256: GLU needs N % 32 == 0";
+  DenseA256 A{X, lda};
+  if (glu) launch256<true>(A, W, nullptr, M, N, K, ep, s); else launch256<false>(A, W, nullptr, M, N, K, ep, s);
+  return nullptr;
+}
+
+const char* launch_conv3x3s2_gemm256(const uint16_t* X, const uint16_t* zero_page, int imgs, int H, int Wd, int C,
+                                     const uint16_t* Wt, int Cout, const GemmEpilogue& ep, hipStream_t s) {
+  if (C % 32 != 0 || 9 * C < 2 * G_BK) return "conv gemm256: C must be a multiple of 32";
+  ConvA256 A{X, zero_page, H, Wd, C, (H - 1) / 2 + 1, (Wd - 1) / 2 + 1};
+  const int M = imgs * A.OH * A.OW;
+  if (M <= 0) return nullptr;
+  launch256<false>(A, Wt, zero_page, M, Cout, 9 * C, ep, s);
+  return nullptr;
+}
+
+}  // namespace q3a

@@ -31,6 +31,14 @@ const char* launch_gemm16(const uint16_t* X, int lda, const uint16_t* W, int M, 
 // zero_page: >= 128 B of zeros (padded filter taps read it)
 const char* launch_conv3x3s2_gemm16(const uint16_t* X, const uint16_t* zero_page, int imgs, int H, int Wd, int C,
                                     const uint16_t* Wt, int Cout, const GemmEpilogue& ep, hipStream_t s);
+// 256 x 256 x 64, 8-wave, counted-vmcnt version of the two above for batch-sized problems (k_gemm256.hip); launch_gemm16 /
+// launch_conv3x3s2_gemm16 dispatch to it when gemm256_eligible (enough 256 x 256 tiles, K % 64 == 0, K >= 128)
+bool gemm256_eligible(int M, int N, int K);
+extern int g_gemm256_min_tiles;  // A/B knob, see k_gemm256.hip
+const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
+                           bool glu, hipStream_t s);
+const char* launch_conv3x3s2_gemm256(const uint16_t* X, const uint16_t* zero_page, int imgs, int H, int Wd, int C,
+                                     const uint16_t* Wt, int Cout, const GemmEpilogue& ep, hipStream_t s);
 // fp32 -> bf16 (round to nearest even), n elements
 const char* launch_to_bf16(const float* x, uint16_t* y, size_t n, hipStream_t s);
 // bf16 -> fp32 (debug taps of bf16 intermediates)

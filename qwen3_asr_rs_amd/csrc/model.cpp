@@ -122,17 +122,17 @@ void Checkpoint::load_file(const std::string& path) {
   int fd = open(path.c_str(), O_RDONLY);
   if (fd < 0) fail("Failed to read safetensors: " + path);
   struct stat st;
-  fstat(fd, &st);
+  if (fstat(fd, &st) != 0) { close(fd); fail("Failed to stat safetensors: " + path); }
   size_t len = (size_t)st.st_size;
+  if (len < 8) { close(fd); fail("Failed to deserialize safetensors (shorter than its 8-byte length prefix): " + path); }
   void* addr = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
   close(fd);
   if (addr == MAP_FAILED) fail("mmap failed: " + path);
   maps_.push_back({addr, len});
   const uint8_t* base = (const uint8_t*)addr;
-  if (len < 8) fail("Failed to deserialize safetensors: " + path);
   uint64_t hlen;
   memcpy(&hlen, base, 8);
-  if (8 + hlen > len) fail("Failed to deserialize safetensors (header length): " + path);
+  if (hlen > len - 8) fail("Failed to deserialize safetensors (header length): " + path);  // no 8 + hlen wrap-around
   Json hdr = JsonParser((const char*)base + 8, (size_t)hlen).parse();
   const uint8_t* data = base + 8 + hlen;
   uint64_t data_len = len - 8 - hlen;

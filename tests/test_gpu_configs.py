@@ -1,0 +1,146 @@
+"""GPU parity (pytest -m gpu) of the BENCHMARKED mode on the BENCHMARKED configurations (BASELINE.json configs[1..3]):
+default bf16 activations / bf16 KV cache, full 30 s clips, the batch sizes bench.py times.
+
+What "token-exact" can mean for a bf16 path against an fp32 oracle: the engine's greedy token must equal the
+oracle's argmax at every step where the oracle's top-1/top-2 logit margin exceeds twice the measured logit error of
+that step (a smaller margin is inside the rounding noise of ANY bf16 implementation, the reference's own bf16 GPU
+builds included).  Each test below therefore
+  * teacher-forces the oracle on the engine's own free-running history (so every step stays comparable),
+  * measures the per-step max |logit error| against the oracle,
+  * asserts exact ids on every over-margin step, counts the flips, and FAILS when more than MAX_UNDER_MARGIN of the
+    steps are under the margin (the bound would otherwise be vacuous) or when any logit error exceeds the tolerance.
+With the synthetic (random-init) checkpoints the logits are nearly flat over 151 936 entries -- top-1/top-2 gaps of
+a few 1e-2 -- which is the hardest case for this criterion; real checkpoints are peaked.
+
+Reference path: src/inference.rs:151-200 (greedy loop), run once per utterance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import q3asr_oracle as O
+from qwen3_asr_rs_amd import synthetic
+from qwen3_asr_rs_amd.engine import HipEngine
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 0.12          # default-mode max |logit error| at 0.6B / 1.7B dims (|logit| <= ~3; measured ~1e-2)
+EMBED_TOL = 2e-2          # rel-L2 of the audio embeddings
+MAX_UNDER_MARGIN = 0.35   # at most this fraction of the compared steps may sit inside the rounding noise
+
+
+def rel_l2(got, ref):
+    got, ref = np.asarray(got, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    return float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))
+
+
+def margin_report(tag, eng_tokens, eng_logits, ref):
+    """eng_tokens[s] / eng_logits[s]: the engine's greedy token and logits at step s (same history as `ref`, an
+    OracleResult produced with forced_ids = the engine's tokens).  Returns (flips, under_margin, worst_err)."""
+    n = len(eng_tokens)
+    flips = under = 0
+    worst = 0.0
+    for s in range(n):
+        ref_l = ref.step_logits[s].numpy()
+        err = float(np.abs(eng_logits[s] - ref_l).max())
+        worst = max(worst, err)
+        top = ref.step_logits[s].topk(2).values
+        margin = float(top[0] - top[1])
+        same = int(eng_tokens[s]) == int(ref.all_step_ids[s])
+        if margin > 2 * err:
+            assert same, f"{tag}: step {s}: engine {int(eng_tokens[s])} != oracle {ref.all_step_ids[s]} with margin {margin:.4f} > 2 x err {err:.4f}"
+        else:
+            under += 1
+        flips += 0 if same else 1
+    print(f"[parity] {tag}: {n} steps, flips {flips}, under-margin {under} ({100.0 * under / n:.1f} %), worst |logit err| {worst:.4f}")
+    assert worst <= LOGIT_TOL, (tag, worst)
+    assert under <= MAX_UNDER_MARGIN * n, f"{tag}: {under}/{n} steps under the margin -- the exact-id bound is vacuous"
+    return flips, under, worst
+
+
+def stepwise_logits(eng, prompts, forced, steps):
+    """Prefill + teacher-forced decode through the stage API: per-step logits [steps][B][V] and greedy tokens."""
+    logits, nxt = eng.prefill(prompts)
+    all_l, all_t = [logits.copy()], [nxt.copy()]
+    for s in range(steps - 1):
+        eng.set_next_tokens([f[s] for f in forced])
+        lg, nx, _ = eng.decode_step()
+        all_l.append(lg.copy())
+        all_t.append(nx.copy())
+    return all_l, all_t
+
+
+def test_config1_0p6b_one_clip_100_tokens_free_running():
+    """BASELINE configs[1], exactly what bench.py times: 0.6B dims, ONE 30 s clip, default mode, 100 greedy tokens
+    free-running from the graph-replayed decode loop."""
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
+    clip = synthetic.synthetic_clip(0, 30.0)
+    N = 100
+    eng = HipEngine(d, 0, max_new_tokens=N)   # same cache capacity (hence key-split count) on both call paths
+    ids = eng.transcribe_batch([clip], None, max_new=N, fixed_new_tokens=N)[0]
+    assert len(ids) == N
+    ref = O.AsrOracle(d).transcribe_ids(clip, forced_ids=ids[:N - 1], last_only=True)
+    assert ref.num_audio_tokens == 390 and ref.prompt_len == 405
+    # engine logits on the same history (eager stage API); its greedy tokens must reproduce the graph-replayed run
+    eng.mel([clip]); eng.encode()
+    L, T = stepwise_logits(eng, [HipEngine.build_prompt(390)], [ids], N)
+    assert [int(t[0]) for t in T] == ids, "stage-API decode differs from the hipGraph-replayed decode"
+    margin_report("config1 0.6B B=1 100 tokens", ids, [l[0] for l in L], ref)
+    eng.close()
+
+
+def _batch_config_check(tag, model_dir, B, check_utts, steps, free_tokens):
+    clips = [synthetic.synthetic_clip(i, 30.0) for i in range(B)]
+    eng = HipEngine(model_dir, 0, max_new_tokens=free_tokens)
+    free = eng.transcribe_batch(clips, None, max_new=free_tokens, fixed_new_tokens=free_tokens)
+    assert len(free) == B and all(len(x) == free_tokens for x in free)
+    eng.mel(clips)
+    emb = eng.encode()
+    L, T = stepwise_logits(eng, [HipEngine.build_prompt(390)] * B, free, steps)
+    for s in range(steps):  # eager stage API == graph-replayed whole path, every utterance of the batch
+        assert [int(x) for x in T[s]] == [free[b][s] for b in range(B)], f"{tag}: step {s} differs between stage API and whole path"
+    orc = O.AsrOracle(model_dir)
+    total_flips = 0
+    for b in check_utts:
+        ref = orc.transcribe_ids(clips[b], forced_ids=free[b][:steps - 1], last_only=True, want_taps=True)
+        assert ref.num_audio_tokens == 390
+        e = rel_l2(emb[b], ref.taps["audio_embeds"].numpy())
+        assert e <= EMBED_TOL, (tag, b, e)
+        fl, _, _ = margin_report(f"{tag} utterance {b}", [free[b][s] for s in range(steps)], [L[s][b] for s in range(steps)], ref)
+        total_flips += fl
+        del ref
+    eng.close()
+    del orc
+    return total_flips
+
+
+def test_config2_0p6b_batch32_30s_default_mode():
+    """BASELINE configs[2]: 0.6B dims, 32 x 30 s clips in ONE batch (encoder GEMMs at M = 12 480, conv2 implicit GEMM at
+    M = 768 000, decode on the skinny MFMA path at 32 sequences).  Three utterances of the batch (first, middle, last)
+    are compared with per-utterance oracle runs: audio embeddings, prefill logits, teacher-forced decode logits,
+    margin-aware exact ids; every utterance's eager decode must equal the graph-replayed one."""
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
+    _batch_config_check("config2 0.6B B=32", d, 32, (0, 15, 31), steps=6, free_tokens=12)
+
+
+def test_config3_1p7b_batch16_30s_default_mode_sharded():
+    """BASELINE configs[3]: 1.7B dims (expected dims), sharded safetensors, 16 x 30 s clips, DEFAULT
+    mode (K = 2048 / 6144 skinny GEMM and LDS-DMA GEMM shapes that the 0.6B checkpoints never reach)."""
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b", "1.7b", seed=0, shards=2)
+    _batch_config_check("config3 1.7B B=16", d, 16, (0, 15), steps=5, free_tokens=8)
+
+
+def test_1p7b_one_clip_default_mode_gemv_path():
+    """1.7B dims at batch 1: the GEMV decode path at K = 2048 / 6144 in the default mode (bench.py --preset 1.7b)."""
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b", "1.7b", seed=0, shards=2)
+    clip = synthetic.synthetic_clip(3, 30.0)
+    N = 12
+    eng = HipEngine(d, 0, max_new_tokens=N)
+    ids = eng.transcribe_batch([clip], None, max_new=N, fixed_new_tokens=N)[0]
+    ref = O.AsrOracle(d).transcribe_ids(clip, forced_ids=ids[:N - 1], last_only=True)
+    eng.mel([clip]); eng.encode()
+    L, T = stepwise_logits(eng, [HipEngine.build_prompt(390)], [ids], N)
+    assert [int(t[0]) for t in T] == ids
+    margin_report("1.7B B=1", ids, [l[0] for l in L], ref)
+    eng.close()
