@@ -323,6 +323,43 @@ def test_parity_0p6b_dims_batch3_skinny_decode():
     del orc, refs
 
 
+def test_engine_against_committed_stage_goldens(tiny_dir):
+    """The HIP path against tests/golden/oracle_stages.npz directly (no oracle code runs): SURVEY.md section 8c(3) per-stage
+    goldens -- conv stem, encoder in/out, audio embeddings, decoder taps, subsampled logits of steps 0 and 8, 16 greedy ids
+    (precise mode: exact ids; default mode: stage tolerances of the module docstring)."""
+    g = np.load(os.path.join(GOLDEN, "oracle_stages.npz"))
+    clip = synthetic.synthetic_clip(0, 9.3)
+    T, P = int(g["T"]), int(g["P"])
+    for precise in (True, False):
+        tol = TOL[precise]
+        eng = HipEngine(tiny_dir, 0, precise=precise, debug_taps=True, max_new_tokens=16)
+        eng.mel([clip])
+        emb = eng.encode()[0]
+        assert emb.shape[0] == T
+        conv3 = eng.debug_read("conv3").reshape(10, 13, 16, -1)   # engine layout [chunk][t][f][c]; golden (chunk, c, f, t)
+        assert rel_l2(conv3.transpose(0, 3, 2, 1)[::3, ::5, :, ::2], g["conv3_q"]) <= tol["rel"]
+        D = g["enc_in_q"].shape[1]
+        assert rel_l2(eng.debug_read("enc_in").reshape(T, D)[::5], g["enc_in_q"]) <= tol["rel"]
+        assert rel_l2(eng.debug_read("enc_last").reshape(T, D)[::5], g["enc_last_q"]) <= tol["rel"]
+        assert rel_l2(emb[::5], g["audio_embeds_q"]) <= tol["rel"]
+        logits, nxt = eng.prefill([HipEngine.build_prompt(T)])
+        H = g["dec_layer0_q"].shape[1]
+        assert rel_l2(eng.debug_read("dec_layer0").reshape(P, H)[::11], g["dec_layer0_q"]) <= tol["rel"]
+        assert rel_l2(eng.debug_read("dec_last_hidden"), g["dec_last_hidden"]) <= tol["rel"]
+        assert float(np.abs(logits[0][::53] - g["logits0_q"]).max()) <= tol["logit"]
+        ids16 = g["ids16"].tolist()
+        toks = [int(nxt[0])]
+        for s in range(8):
+            eng.set_next_tokens([ids16[s]])
+            lg, nx, _ = eng.decode_step()
+            toks.append(int(nx[0]))
+        assert float(np.abs(lg[0][::53] - g["logits8_q"]).max()) <= tol["logit"]
+        if precise:
+            assert toks == ids16[:9]
+            assert eng.transcribe_batch([clip], None, max_new=16, fixed_new_tokens=16)[0] == ids16
+        eng.close()
+
+
 def test_cli_end_to_end(tiny_dir, tmp_path):
     """`asr <model_dir> <wav> [language]` (src/main.rs:7-81): stdout contract and agreement with the library path.
     The model directory gets a synthetic tokenizer.json (id i <-> token "t{i}", two special ids)."""

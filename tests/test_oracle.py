@@ -91,6 +91,52 @@ def test_oracle_frozen_outputs(tiny_oracle):
     assert r.all_step_ids == g["ids"].tolist()
 
 
+def test_oracle_matches_independent_hf_transformers_implementation(tiny_oracle, tiny_untied_dir):
+    """tests/golden/hf_pin.npz: outputs of HuggingFace transformers' own `qwen3_asr` model (written by other people
+    from the original Python model; different op sequence and checkpoint naming) on the seeded synthetic checkpoints,
+    loaded through a key remap (tests/golden/make_hf_pin.py).  Three cases: two attention windows, a ragged last chunk,
+    untied lm_head + GQA ratio 4 + contiguous mrope map.  The oracle must agree to fp32 rounding: audio embeddings,
+    last-row logits, the top-4 vocabulary indices of 9 consecutive steps and 8 greedy ids."""
+    g = np.load(os.path.join(GOLDEN, "hf_pin.npz"))
+    cases = [("tiny", tiny_oracle, synthetic.synthetic_clip(0, 9.3)), ("tiny_short", tiny_oracle, synthetic.synthetic_clip(1, 2.17)),
+             ("untied", O.AsrOracle(tiny_untied_dir), synthetic.synthetic_clip(2, 4.0))]
+    for name, orc, clip in cases:
+        r = orc.transcribe_ids(clip, fixed_new_tokens=9, want_taps=True)
+        assert r.num_audio_tokens == int(g[f"{name}_T"])
+        ae = r.taps["audio_embeds"].numpy()
+        np.testing.assert_allclose(ae[::7], g[f"{name}_audio_embeds_q"], atol=2e-6)          # |embeds| <= 0.15
+        assert abs(float(ae.astype(np.float64).sum()) - float(g[f"{name}_audio_embeds_sum"])) < 1e-4
+        np.testing.assert_allclose(r.step_logits[0].numpy()[::97], g[f"{name}_logits0_q"], atol=2e-5)   # |logits| <= 1.6
+        assert r.all_step_ids[:8] == g[f"{name}_ids"].tolist()
+        for s in range(9):
+            top = r.step_logits[s].topk(4)
+            assert top.indices.tolist() == g[f"{name}_top_idx"][s].tolist(), (name, s)
+            np.testing.assert_allclose(top.values.numpy(), g[f"{name}_top_val"][s], atol=2e-5)
+
+
+def test_oracle_stage_goldens(tiny_oracle):
+    """per-stage goldens (conv stem, window segments of a 10-chunk input, cos/sin tables, encoder
+    and decoder taps, 16 greedy ids) -- tests/golden/oracle_stages.npz, which the HIP engine is held to as well."""
+    g = np.load(os.path.join(GOLDEN, "oracle_stages.npz"))
+    clip = synthetic.synthetic_clip(0, 9.3)
+    assert len(clip) == int(g["n_samples"])
+    r = tiny_oracle.transcribe_ids(clip, fixed_new_tokens=16, want_taps=True)
+    t = r.taps
+    assert (r.num_audio_tokens, r.prompt_len) == (int(g["T"]), int(g["P"]))
+    assert O.window_segments([13] * 9 + [O.feat_extract_output_length(30)], 50, 800) == g["window_segments"].tolist() == [104, 17]
+    np.testing.assert_allclose(t["conv3"].numpy()[::3, ::5, :, ::2], g["conv3_q"], atol=1e-5)
+    for k in ("enc_in", "enc_last", "audio_embeds"):
+        np.testing.assert_allclose(t[k].numpy()[::5], g[k + "_q"], atol=1e-5, err_msg=k)
+    tc = tiny_oracle.cfg.text
+    cos, sin = O.compute_mrope_cos_sin([list(range(r.prompt_len + 16))] * 3, tc.head_dim, tc.rope_theta, tc.mrope_section, tc.mrope_interleaved)
+    assert np.array_equal(cos.numpy()[::9, :64], g["rope_cos_q"]) and np.array_equal(sin.numpy()[::9, :64], g["rope_sin_q"])
+    np.testing.assert_allclose(t["dec_layer0"].numpy()[::11], g["dec_layer0_q"], atol=1e-5)
+    np.testing.assert_allclose(t["dec_last_hidden"].numpy(), g["dec_last_hidden"], atol=1e-5)
+    np.testing.assert_allclose(r.step_logits[0].numpy()[::53], g["logits0_q"], atol=1e-4)
+    np.testing.assert_allclose(r.step_logits[8].numpy()[::53], g["logits8_q"], atol=1e-4)
+    assert r.all_step_ids == g["ids16"].tolist()
+
+
 def test_oracle_teacher_forcing_equals_free_running(tiny_oracle):
     clip = synthetic.synthetic_clip(3, 2.5)
     a = tiny_oracle.transcribe_ids(clip, fixed_new_tokens=3)
