@@ -366,7 +366,9 @@ struct q3a_engine {
     const size_t Tt = (size_t)total_T;
     // the fp32 VALU attention (precise mode / opts.valu_attention) writes an fp32 context that is rounded afterwards
     const bool valu_attn = sp || opts.valu_attention;
-    enc_x.ensure(Tt * D * 4); enc_ln.ensure(Tt * D * ae); enc_qkv.ensure(Tt * 3 * D * 4);
+    // the MFMA attention consumes q/k/v as bf16: the qkv GEMM then stores exactly those values (half the bytes)
+    const bool qkv16 = !valu_attn;
+    enc_x.ensure(Tt * D * 4); enc_ln.ensure(Tt * D * ae); enc_qkv.ensure(Tt * 3 * D * (qkv16 ? 2 : 4));
     enc_ctx.ensure(Tt * D * (valu_attn ? 4 : ae));
     if (valu_attn && !sp) enc_ctx16.ensure(Tt * D * 2);
     enc_ffn.ensure(Tt * Fn * ae); audio_embeds.ensure(Tt * d.enc_out * 4);
@@ -399,6 +401,10 @@ struct q3a_engine {
     AttnArgs at{};
     at.q = enc_qkv.as<float>(); at.q_rs = 3 * D;
     at.k = enc_qkv.as<float>() + D; at.v = enc_qkv.as<float>() + 2 * D; at.kv_hs = 64; at.kv_rs = 3 * D;
+    if (qkv16) {
+      at.q16 = enc_qkv.as<uint16_t>();
+      at.k = enc_qkv.as<uint16_t>() + D; at.v = enc_qkv.as<uint16_t>() + 2 * D;
+    }
     at.o = enc_ctx.as<float>(); at.o_rs = D;
     at.o16 = valu_attn ? nullptr : enc_ctx.as<uint16_t>();
     at.segs = enc_segs.as<AttnSeg>(); at.n_segs = (int)enc_segs_h.size(); at.max_len = enc_max_seg;
@@ -408,7 +414,8 @@ struct q3a_engine {
       const EncLayerOff& e = L.enc[li];
       KCHK(launch_layernorm(enc_x.as<float>(), wf(e.ln1_w), wf(e.ln1_b), enc_ln.as<float>(), total_T, D, 1e-5f, stream, act16(enc_ln)));
       {
-        GemmEpilogue ep; ep.out = enc_qkv.as<float>(); ep.ldo = 3 * D; ep.bias = wf(e.qkv_b);
+        GemmEpilogue ep; ep.ldo = 3 * D; ep.bias = wf(e.qkv_b);
+        if (qkv16) ep.out16 = enc_qkv.as<uint16_t>(); else ep.out = enc_qkv.as<float>();
         act_gemm(enc_ln, D, wh(e.qkv_w), total_T, 3 * D, D, ep, false);
       }
       if (valu_attn) {

@@ -68,7 +68,11 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
 
   // ---- Q^T fragments (B operand): lane holds Q[qi][ks*16 + half*8 .. +8] as bf16 ----
   bf16x8_t qfrag[KS];
-  {
+  if (a.q16) {  // Q already rounded to bf16 by the producing GEMM's epilogue (the very values the conversion below yields)
+    const uint16_t* qrow = a.q16 + (size_t)(seg.q_row0 + (qi < seg.len ? qi : seg.len - 1)) * a.q_rs + head * HD;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qfrag[ks] = *reinterpret_cast<const bf16x8_t*>(qrow + ks * 16 + half * 8);
+  } else {
     const float* qrow = a.q + (size_t)(seg.q_row0 + (qi < seg.len ? qi : seg.len - 1)) * a.q_rs + head * HD;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -231,7 +235,12 @@ void launch_f(const AttnArgs& a, hipStream_t s) {
 const char* launch_fattn_enc(const AttnArgs& a, hipStream_t s) {
   if (a.n_segs <= 0) return nullptr;
   if (a.q_rs % 4 != 0 || a.kv_rs % 4 != 0 || a.o_rs % 4 != 0) return "fattn: row strides must be multiples of 4";
-  launch_f<64, 1, false, float>(a, s);
+  if (a.q16) {  // bf16 q/k/v projections (k and v point into the same bf16 buffer)
+    if (a.q_rs % 8 != 0 || a.kv_rs % 8 != 0) return "fattn: bf16 row strides must be multiples of 8";
+    launch_f<64, 1, false, uint16_t>(a, s);
+  } else {
+    launch_f<64, 1, false, float>(a, s);
+  }
   return nullptr;
 }
 

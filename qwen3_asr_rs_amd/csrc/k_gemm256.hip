@@ -9,11 +9,12 @@
 // Structure (cdna_hip_programming.md "256^2 8-phase template", re-derived here because its source is not in the image):
 //   * workgroup = 8 waves = 2 (M) x 4 (N); a wave owns a 128 x 64 output tile = 8 x 4 fragments of
 //     v_mfma_f32_16x16x32_bf16 (128 accumulator registers);
-//   * LDS = 2 K-tile buffers x (A 256 x 64 + B 256 x 64) bf16 = 128 KiB, ONE __shared__ array.  A buffer is made of 1 KiB
-//     subtiles of 16 rows x 32 k: exactly what ONE global_load_lds wave instruction writes and what ONE ds_read_b128
-//     fragment read consumes.  Inside a subtile the 16-B chunk c of row r sits at chunk position c ^ ((r >> 3) << 1)
-//     (the guide's st_16x32 swizzle: byte ^= ((byte >> 9) & 1) << 5); the LDS-DMA image is lane-linear, so the
-//     permutation is applied to the SOURCE address and again to the read address: conflict-free ds_read_b128;
+//   * LDS = 2 K-tile buffers x (A 256 x 64 + B 256 x 64) bf16 = 128 KiB, ONE __shared__ array, rows of 128 B (one K tile
+//     row = one cache line).  One global_load_lds wave instruction fills 8 rows (1 KiB, 8 full cache lines: half the
+//     line touches of a 16-row x 64-B fragment-shaped load).  The 16-B chunk c of row r sits at chunk position
+//     c ^ ((r >> 1) & 7); the LDS-DMA image is lane-linear, so the permutation is applied to the SOURCE address (inside
+//     one cache line) and again to the fragment read address: the 16 lanes of a ds_read_b128 group hit 16 distinct
+//     16-B bank slots;
 //   * a K tile is consumed in 4 phases of 16 MFMAs per wave (one 64 x 32 quadrant of the wave tile x K = 64):
 //         P1  read A rows m0 (8 reads) + B rows n0 (4)     MFMA m0 x n0
 //         P2  read B rows n1 (4)                            MFMA m0 x n1
@@ -46,47 +47,52 @@ constexpr int G_BUF = 65536;    // bytes per K-tile buffer: A 32 KiB then B 32 K
 constexpr int G_BOFF = 32768;   // B region inside a buffer
 
 // ---- A-operand views --------------------------------------------------------------------------------------------
-// Row state is per lane: the lane stages 16 B of ONE row per LDS-DMA instruction.  src(k) returns the address of the
-// 8 bf16 at column k (k = tile k0 + half * 32; the lane's swizzled chunk offset is folded into the row state).
+// Row state is per lane and per LDS-DMA instruction: the lane stages 16 B (8 bf16) of ONE row of the K tile,
+// source chunk `chunk` (0..7) of the row's 64 columns.  src(row, ka, kb): ka / kb = column iterators of the first / second
+// 32-column half of the tile (wave-uniform); the lane's half is chunk >> 2.
 struct DenseA256 {
   const uint16_t* x;
   int lda;
   struct Row { const uint16_t* p; };
-  __device__ __forceinline__ Row init(int m, int M, int chunk_elems) const {
+  __device__ __forceinline__ Row init(int m, int M, int chunk) const {
     if (m >= M) m = M - 1;  // tail rows are clamped: their products are never stored
-    return Row{x + (size_t)m * lda + chunk_elems};
+    return Row{x + (size_t)m * lda + chunk * 8};
   }
-  typedef int KIter;  // column of the 32-wide half row being staged (wave-uniform)
+  typedef int KIter;  // first column of a 32-wide half
   __device__ __forceinline__ KIter kbegin() const { return 0; }
   __device__ __forceinline__ void knext(KIter& k) const { k += 32; }
-  __device__ __forceinline__ const uint16_t* src(const Row& r, const KIter& k) const { return r.p + k; }
+  __device__ __forceinline__ const uint16_t* src(const Row& r, const KIter& ka, const KIter&) const { return r.p + ka; }
 };
 
 // im2col view of an NHWC bf16 feature map [img][H][W][C] for a 3x3 stride-2 pad-1 convolution; K = 9 * C ordered
-// (kh, kw, c).  C % 32 == 0, so a 32-wide half row of a K tile never straddles two filter taps.
+// (kh, kw, c).  C % 32 == 0, so a 32-wide half row of a K tile never straddles two filter taps (the two halves may).
 struct ConvA256 {
   const uint16_t* x;
-  const uint16_t* zero;  // >= 64 B of zeros for padded taps
+  const uint16_t* zero;  // >= 128 B of zeros for padded taps and for the half tile past K (K % 64 == 32)
   int H, W, C, OH, OW;
-  struct Row { int img, ih0, iw0, chunk; };
-  __device__ __forceinline__ Row init(int m, int M, int chunk_elems) const {
+  struct Row { long base; int ih0, iw0, chunk; };  // base: element offset of (img, ih0, iw0, channel 0) -- may point before a row
+  __device__ __forceinline__ Row init(int m, int M, int chunk) const {
     if (m >= M) m = M - 1;
     const int img = m / (OH * OW);
     const int r = m - img * OH * OW;
     const int oh = r / OW, ow = r - oh * OW;
-    return Row{img, oh * 2 - 1, ow * 2 - 1, chunk_elems};
+    const int ih0 = oh * 2 - 1, iw0 = ow * 2 - 1;
+    return Row{(((long)img * H + ih0) * W + iw0) * C, ih0, iw0, chunk};
   }
-  struct KIter { int kh, kw, c0; };  // filter tap and first channel of the 32-wide half row (wave-uniform: scalar registers)
+  struct KIter { int kh, kw, c0; };  // filter tap and first channel of a 32-wide half (wave-uniform: scalar registers)
   __device__ __forceinline__ KIter kbegin() const { return KIter{0, 0, 0}; }
   __device__ __forceinline__ void knext(KIter& k) const {
     k.c0 += 32;
     if (k.c0 >= C) { k.c0 = 0; if (++k.kw == 3) { k.kw = 0; ++k.kh; } }
   }
-  __device__ __forceinline__ const uint16_t* src(const Row& r, const KIter& k) const {
-    const int ih = r.ih0 + k.kh, iw = r.iw0 + k.kw;
-    const bool ok = k.kh < 3 && ih >= 0 && ih < H && iw >= 0 && iw < W;  // kh == 3: the zero half tile past K = 9 * C
-    const uint16_t* p = x + (((size_t)r.img * H + ih) * W + iw) * C + k.c0 + r.chunk;
-    return ok ? p : zero + r.chunk;
+  __device__ __forceinline__ const uint16_t* src(const Row& r, const KIter& ka, const KIter& kb) const {
+    const bool hb = r.chunk >= 4;  // this lane's half of the tile
+    const int kh = hb ? kb.kh : ka.kh, kw = hb ? kb.kw : ka.kw;
+    const int toff = hb ? (kb.kh * W + kb.kw) * C + kb.c0 : (ka.kh * W + ka.kw) * C + ka.c0;  // scalar products, one select
+    const int ih = r.ih0 + kh, iw = r.iw0 + kw;
+    const bool ok = kh < 3 && ih >= 0 && ih < H && iw >= 0 && iw < W;  // kh == 3: the zero half tile past K = 9 * C
+    const int sub = (r.chunk & 3) * 8;
+    return ok ? x + (r.base + toff + sub) : zero + sub;
   }
 };
 
@@ -121,38 +127,41 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  // ---- staging assignment: per unit a wave fills the two 1 KiB subtiles (k halves) of ONE 16-row block ----
-  const int srow = lane >> 2;                                 // row inside the 16-row block
-  const int schunk = ((lane & 3) ^ (((lane >> 5) & 1) << 1)) * 8;  // swizzled source chunk (elements) inside the 32-wide half row
+  // ---- staging assignment: per unit a wave fills ONE 16-row block with two LDS-DMA instructions of 8 rows x 128 B ----
+  // instruction j: tile row rb*16 + j*8 + (lane >> 3), LDS chunk position lane & 7 = source chunk ^ ((row >> 1) & 7)
+  const int srow = lane >> 3;
+  const int sch0 = (lane & 7) ^ ((lane >> 4) & 7), sch1 = sch0 ^ 4;  // source chunks of instructions 0 / 1
   const int rbA0 = wave + (wave >= 4 ? 4 : 0), rbA1 = rbA0 + 4;    // A-m0: row blocks {0-3, 8-11}; A-m1: {4-7, 12-15}
   const int rbB0 = (wave >> 1) * 4 + (wave & 1), rbB1 = rbB0 + 2;  // B-n0: {0,1,4,5,..}; B-n1: {2,3,6,7,..}
-  const typename ALoader::Row rowA0 = A.init(m0 + rbA0 * 16 + srow, M, schunk);
-  const typename ALoader::Row rowA1 = A.init(m0 + rbA1 * 16 + srow, M, schunk);
-  const uint16_t* rowB0;
-  const uint16_t* rowB1;
-  {
-    const int nb0 = n0 + rbB0 * 16 + srow, nb1 = n0 + rbB1 * 16 + srow;
-    rowB0 = Wt + (size_t)(nb0 < N ? nb0 : N - 1) * K + schunk;
-    rowB1 = Wt + (size_t)(nb1 < N ? nb1 : N - 1) * K + schunk;
-  }
+  typedef typename ALoader::Row ARow;
+  const ARow rowA0a = A.init(m0 + rbA0 * 16 + srow, M, sch0), rowA0b = A.init(m0 + rbA0 * 16 + 8 + srow, M, sch1);
+  const ARow rowA1a = A.init(m0 + rbA1 * 16 + srow, M, sch0), rowA1b = A.init(m0 + rbA1 * 16 + 8 + srow, M, sch1);
+  auto brow = [&](int n, int ch) { return Wt + (size_t)(n < N ? n : N - 1) * K + ch * 8; };
+  const uint16_t* rowB0a = brow(n0 + rbB0 * 16 + srow, sch0);
+  const uint16_t* rowB0b = brow(n0 + rbB0 * 16 + 8 + srow, sch1);
+  const uint16_t* rowB1a = brow(n0 + rbB1 * 16 + srow, sch0);
+  const uint16_t* rowB1b = brow(n0 + rbB1 * 16 + 8 + srow, sch1);
   const int dA0 = rbA0 * 2048, dA1 = rbA1 * 2048, dB0 = G_BOFF + rbB0 * 2048, dB1 = G_BOFF + rbB1 * 2048;  // wave-uniform
 
   typedef typename ALoader::KIter KIter;
-  auto stage_a = [&](const typename ALoader::Row& r, const KIter& ka, const KIter& kb, int dst) {  // ka / kb: the two k halves
-    __builtin_amdgcn_global_load_lds((gptr_t)A.src(r, ka), (lptr_t)(lds + dst), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gptr_t)A.src(r, kb), (lptr_t)(lds + dst + 1024), 16, 0, 0);
+  auto stage_a = [&](const ARow& ra, const ARow& rb, const KIter& ka, const KIter& kb, int dst) {  // ka / kb: the two k halves
+    __builtin_amdgcn_global_load_lds((gptr_t)A.src(ra, ka, kb), (lptr_t)(lds + dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)A.src(rb, ka, kb), (lptr_t)(lds + dst + 1024), 16, 0, 0);
   };
   // K % 64 == 32 (the convolutions: K = 9 * 480): the second half of the last tile is read from the zero page on both sides
-  auto stage_b = [&](const uint16_t* r, int k0, int dst) {
-    __builtin_amdgcn_global_load_lds((gptr_t)(r + k0), (lptr_t)(lds + dst), 16, 0, 0);
-    const uint16_t* h1 = k0 + 32 < K ? r + k0 + 32 : zero + schunk;  // wave-uniform condition
-    __builtin_amdgcn_global_load_lds((gptr_t)h1, (lptr_t)(lds + dst + 1024), 16, 0, 0);
+  auto stage_b = [&](const uint16_t* ra, const uint16_t* rb, int k0, int dst) {
+    const bool tail = k0 + 32 >= K;  // wave-uniform
+    const uint16_t* pa = tail && sch0 >= 4 ? zero + (sch0 & 3) * 8 : ra + k0;
+    const uint16_t* pb = tail && sch1 >= 4 ? zero + (sch1 & 3) * 8 : rb + k0;
+    __builtin_amdgcn_global_load_lds((gptr_t)pa, (lptr_t)(lds + dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)pb, (lptr_t)(lds + dst + 1024), 16, 0, 0);
   };
 
-  // ---- fragment read addresses: lane reads row (lane & 15), logical chunk (lane >> 4) of a subtile ----
-  const int roff = (lane & 15) * 64 + (((lane >> 4) ^ (((lane & 15) >> 3) << 1)) * 16);
-  const int ra_base = wr * 16384 + roff;            // A subtile (i, ks) of this wave: + (i * 2 + ks) * 1024
-  const int rb_base = G_BOFF + wc * 8192 + roff;    // B subtile (j, ks):              + (j * 2 + ks) * 1024
+  // ---- fragment read addresses: lane reads row r = lane & 15, logical chunk ks * 4 + (lane >> 4) of a 16-row block ----
+  const int fr = lane & 15, ft = (lane >> 4) ^ ((fr >> 1) & 7);
+  const int roff0 = fr * 128 + ft * 16, roff1 = fr * 128 + (ft ^ 4) * 16;  // k-step 0 / 1
+  const int ra_base = wr * 16384;            // A block i of this wave: + i * 2048
+  const int rb_base = G_BOFF + wc * 8192;    // B block j:              + j * 2048
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -171,12 +180,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
     A.knext(kit);  // column 64
     KIter k11 = kit;
     A.knext(k11);
-    stage_a(rowA0, k00, k01, dA0);
-    stage_b(rowB0, 0, dB0);
-    stage_b(rowB1, 0, dB1);
-    stage_a(rowA1, k00, k01, dA1);
-    stage_a(rowA0, kit, k11, G_BUF + dA0);
-    stage_b(rowB0, G_BK, G_BUF + dB0);
+    stage_a(rowA0a, rowA0b, k00, k01, dA0);
+    stage_b(rowB0a, rowB0b, 0, dB0);
+    stage_b(rowB1a, rowB1b, 0, dB1);
+    stage_a(rowA1a, rowA1b, k00, k01, dA1);
+    stage_a(rowA0a, rowA0b, kit, k11, G_BUF + dA0);
+    stage_b(rowB0a, rowB0b, G_BK, G_BUF + dB0);
   }
   Q3A_WAIT_VM(8);  // A-m0(0), B-n0(0) have landed (this wave's part)
   Q3A_BARRIER();
@@ -196,15 +205,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
     const KIter ka2 = kit;
     KIter kb2 = kit;
     A.knext(kb2);
-    const bf16x8_t* ap = reinterpret_cast<const bf16x8_t*>(lds + cb + ra_base);
-    const bf16x8_t* bp = reinterpret_cast<const bf16x8_t*>(lds + cb + rb_base);
+    const bf16x8_t* ap0 = reinterpret_cast<const bf16x8_t*>(lds + cb + ra_base + roff0);
+    const bf16x8_t* ap1 = reinterpret_cast<const bf16x8_t*>(lds + cb + ra_base + roff1);
+    const bf16x8_t* bp0 = reinterpret_cast<const bf16x8_t*>(lds + cb + rb_base + roff0);
+    const bf16x8_t* bp1 = reinterpret_cast<const bf16x8_t*>(lds + cb + rb_base + roff1);
     // ---------------- P1 ----------------
 #pragma unroll
-    for (int q = 0; q < 4; ++q) b0f[q] = bp[q * 64];          // B n0: j = 0,1 x ks = 0,1  (subtile index j*2+ks = q)
+    for (int j = 0; j < 2; ++j) { b0f[j * 2] = bp0[j * 128]; b0f[j * 2 + 1] = bp1[j * 128]; }       // B n0: blocks 0,1
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) af[q] = ap[q * 64];           // A m0: i = 0..3 x ks
-    if constexpr (N1) stage_b(rowB1, k1, nb + dB1);
+    for (int i = 0; i < 4; ++i) { af[i * 2] = ap0[i * 128]; af[i * 2 + 1] = ap1[i * 128]; }          // A m0: blocks 0..3
+    if constexpr (N1) stage_b(rowB1a, rowB1b, k1, nb + dB1);
     wait_vm<N1 ? 8 : 2>();                                    // B-n1(t) has landed
     __builtin_amdgcn_sched_barrier(0);
     Q3A_BARRIER();
@@ -223,8 +234,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
     Q3A_BARRIER();
     // ---------------- P2 ----------------
 #pragma unroll
-    for (int q = 0; q < 4; ++q) b1f[q] = bp[(4 + q) * 64];    // B n1: j = 2,3
-    if constexpr (N1) stage_a(rowA1, ka1, kb1, nb + dA1);
+    for (int j = 0; j < 2; ++j) { b1f[j * 2] = bp0[(2 + j) * 128]; b1f[j * 2 + 1] = bp1[(2 + j) * 128]; }  // B n1: blocks 2,3
+    if constexpr (N1) stage_a(rowA1a, rowA1b, ka1, kb1, nb + dA1);
     wait_vm<N1 ? 8 : 0>();                                    // A-m1(t) has landed
     __builtin_amdgcn_sched_barrier(0);
     Q3A_BARRIER();
@@ -243,8 +254,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
     Q3A_BARRIER();
     // ---------------- P3 ----------------
 #pragma unroll
-    for (int q = 0; q < 8; ++q) af[q] = ap[(8 + q) * 64];     // A m1: i = 4..7
-    if constexpr (N2) stage_a(rowA0, ka2, kb2, cb + dA0);           // A-m0 / B-n0 of this buffer were last read in P1
+    for (int i = 0; i < 4; ++i) { af[i * 2] = ap0[(4 + i) * 128]; af[i * 2 + 1] = ap1[(4 + i) * 128]; }  // A m1: blocks 4..7
+    if constexpr (N2) stage_a(rowA0a, rowA0b, ka2, kb2, cb + dA0);  // A-m0 / B-n0 of this buffer were last read in P1
     __builtin_amdgcn_sched_barrier(0);
     Q3A_BARRIER();
     Q3A_WAIT_LGKM0();
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
     __builtin_amdgcn_sched_barrier(0);
     Q3A_BARRIER();
     // ---------------- P4 ----------------
-    if constexpr (N2) stage_b(rowB0, k2, cb + dB0);
+    if constexpr (N2) stage_b(rowB0a, rowB0b, k2, cb + dB0);
     if constexpr (N1) wait_vm<N2 ? 8 : 4>();                  // A-m0(t+1), B-n0(t+1) have landed
     __builtin_amdgcn_sched_barrier(0);
     Q3A_BARRIER();
@@ -283,41 +294,79 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
     tile(t, std::true_type{}, std::false_type{});
     tile(t + 1, std::false_type{}, std::false_type{});
   }
-  if (wr == 0) Q3A_BARRIER();  // balance the extra barrier of the second group
+  if (wr == 0) Q3A_BARRIER();  // balance the extra barrier of the second group: every wave is past its last LDS read
 
-  // ---- epilogue (C/D layout of v_mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg) ----
+  // ---- epilogue: the wave's 128 x 64 tile goes through its private 16 KiB of LDS in two 64-row passes, so that global
+  // memory sees whole rows: 256 B (fp32) / 128 B (bf16) contiguous per row instead of the 64-B column slices of the MFMA
+  // C/D layout (col = lane & 15, row = (lane >> 4) * 4 + reg) ----
+  float* stg = reinterpret_cast<float*>(lds + wave * 16384);  // [64][64] fp32
   const int col_in = lane & 15, row_in = (lane >> 4) * 4;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wr * 128 + i * 16 + row_in + r;
-      if (m >= M) continue;
-      const int orow = ep.rowmap ? ep.rowmap[m] : m;
-      if (orow < 0) continue;
-      if (!GLU) {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = n0 + wc * 64 + j * 16 + col_in;
-          if (n >= N) continue;
-          float v = acc[i][j][r];
-          if (ep.bias) v += ep.bias[n];
-          if (ep.addend) v += ep.addend[(size_t)(m % ep.addend_period) * ep.ldo + n];
-          if (ep.act == 1) v = gelu_fast(v);  // default mode: the result is rounded to bf16 (dev.h)
-          if (ep.resid) v += ep.resid[(size_t)orow * ep.ldo + n];
-          if (ep.out16) ep.out16[(size_t)orow * ep.ldo + n] = (uint16_t)f32_to_bf16_bits(v);
-          else ep.out[(size_t)orow * ep.ldo + n] = v;
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[(i * 16 + row_in + r) * 64 + j * 16 + col_in] = acc[h * 4 + i][j][r];
+    const int mrow0 = m0 + wr * 128 + h * 64;
+    if (!GLU) {
+      const int c4 = (lane & 15) * 4, n = n0 + wc * 64 + c4;
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4), m = mrow0 + row;
+        float4 v = *reinterpret_cast<const float4*>(&stg[row * 64 + c4]);
+        if (m >= M || n >= N) continue;
+        const int orow = ep.rowmap ? ep.rowmap[m] : m;
+        if (orow < 0) continue;
+        if (ep.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(ep.bias + n);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j + 1 < 4; j += 2) {
-          const int nb = n0 + wc * 64 + j * 16;
-          if (nb + 16 + col_in >= N) continue;
-          float g = acc[i][j][r], u = acc[i][j + 1][r];
-          if (ep.bias) { g += ep.bias[nb + col_in]; u += ep.bias[nb + 16 + col_in]; }
-          const float v = silu_fast(g) * u;
-          if (ep.out16) ep.out16[(size_t)orow * ep.ldo + (nb >> 1) + col_in] = (uint16_t)f32_to_bf16_bits(v);
-          else ep.out[(size_t)orow * ep.ldo + (nb >> 1) + col_in] = v;
+        if (ep.addend) {
+          const float4 b = *reinterpret_cast<const float4*>(ep.addend + (size_t)(m % ep.addend_period) * ep.ldo + n);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (ep.act == 1) { v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w); }
+        if (ep.resid) {
+          const float4 b = *reinterpret_cast<const float4*>(ep.resid + (size_t)orow * ep.ldo + n);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (ep.out16) {
+          uint2 pk;
+          pk.x = pack_bf16x2(v.x, v.y);
+          pk.y = pack_bf16x2(v.z, v.w);
+          *reinterpret_cast<uint2*>(ep.out16 + (size_t)orow * ep.ldo + n) = pk;
+        } else {
+          *reinterpret_cast<float4*>(ep.out + (size_t)orow * ep.ldo + n) = v;
+        }
+      }
+    } else {
+      // W rows are [16 gate | 16 up] blocks: staged columns [0,16) gate / [16,32) up of output columns 0..15, [32,64) likewise
+      const int oc4 = (lane & 7) * 4, gc = (oc4 >> 4) * 32 + (oc4 & 15);
+      const int nb = n0 + wc * 64 + gc;          // W row of the gate value
+      const int on = ((n0 + wc * 64) >> 1) + oc4;  // output column
+#pragma unroll 4
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), m = mrow0 + row;
+        float4 g = *reinterpret_cast<const float4*>(&stg[row * 64 + gc]);
+        float4 u = *reinterpret_cast<const float4*>(&stg[row * 64 + gc + 16]);
+        if (m >= M || nb + 16 >= N) continue;
+        const int orow = ep.rowmap ? ep.rowmap[m] : m;
+        if (orow < 0) continue;
+        if (ep.bias) {
+          const float4 bg = *reinterpret_cast<const float4*>(ep.bias + nb), bu = *reinterpret_cast<const float4*>(ep.bias + nb + 16);
+          g.x += bg.x; g.y += bg.y; g.z += bg.z; g.w += bg.w;
+          u.x += bu.x; u.y += bu.y; u.z += bu.z; u.w += bu.w;
+        }
+        const float4 v = make_float4(silu_fast(g.x) * u.x, silu_fast(g.y) * u.y, silu_fast(g.z) * u.z, silu_fast(g.w) * u.w);
+        if (ep.out16) {
+          uint2 pk;
+          pk.x = pack_bf16x2(v.x, v.y);
+          pk.y = pack_bf16x2(v.z, v.w);
+          *reinterpret_cast<uint2*>(ep.out16 + (size_t)orow * ep.ldo + on) = pk;
+        } else {
+          *reinterpret_cast<float4*>(ep.out + (size_t)orow * ep.ldo + on) = v;
         }
       }
     }
@@ -340,7 +389,7 @@ bool gemm256_eligible(int M, int N, int K) {
     const char* e = getenv("Q3A_GEMM256_MIN_TILES");
     g_gemm256_min_tiles = e ? atoi(e) : 128;
   }
-  if (K % 32 != 0 || K < 2 * G_BK) return false;
+  if (K % 32 != 0 || K < 2 * G_BK || N % 4 != 0) return false;
   const long tiles = (long)((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
   return tiles >= g_gemm256_min_tiles;
 }
@@ -350,6 +399,7 @@ const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M,
   if (M <= 0) return nullptr;
   if (K % G_BK != 0 || K < 2 * G_BK || lda % 8 != 0) return "gemm256: K must be a multiple of 64 (>= 128) and lda of 8";
   if (glu && N % 32 != 0) return "gemm256: GLU needs N % 32 == 0";
+  if (N % 4 != 0 || ep.ldo % 4 != 0) return "gemm256: N and ldo must be multiples of 4 (vector epilogue)";
   DenseA256 A{X, lda};
   if (glu) launch256<true>(A, W, nullptr, M, N, K, ep, s); else launch256<false>(A, W, nullptr, M, N, K, ep, s);
   return nullptr;
@@ -358,6 +408,7 @@ const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M,
 const char* launch_conv3x3s2_gemm256(const uint16_t* X, const uint16_t* zero_page, int imgs, int H, int Wd, int C,
                                      const uint16_t* Wt, int Cout, const GemmEpilogue& ep, hipStream_t s) {
   if (C % 32 != 0 || 9 * C < 2 * G_BK) return "conv gemm256: C must be a multiple of 32";
+  if (Cout % 4 != 0 || ep.ldo % 4 != 0) return "conv gemm256: Cout and ldo must be multiples of 4 (vector epilogue)";
   ConvA256 A{X, zero_page, H, Wd, C, (H - 1) / 2 + 1, (Wd - 1) / 2 + 1};
   const int M = imgs * A.OH * A.OW;
   if (M <= 0) return nullptr;

@@ -86,6 +86,7 @@ struct AttnSeg {
 };
 struct AttnArgs {
   const float* q; int q_rs;
+  const uint16_t* q16;  // MFMA flash attention only: when non-null, Q is read from here as bf16 (same strides) instead of q
   const void* k; const void* v; int64_t kv_hs; int kv_rs;
   float* o; int o_rs;
   uint16_t* o16;    // MFMA flash attention only: when non-null the output is written here as bf16 (same strides)
