@@ -174,6 +174,12 @@ int32_t q3a_debug_read(q3a_engine* e, const char* name, void* dst, uint64_t byte
  * *samples_out is malloc'ed; release it with q3a_free. */
 int32_t q3a_load_audio(const char* path, int32_t target_sr, float** samples_out, int64_t* n_out);
 int32_t q3a_resample(const float* in, int64_t n, int32_t sr_in, int32_t sr_out, float** samples_out, int64_t* n_out);
+/* The reference's WAV-fallback resampler (src/audio.rs:220-245: rubato SincFixedIn, sinc_len 256, f_cutoff 0.95, Linear,
+ * oversampling 256, BlackmanHarris2, one `process` call over the whole clip), restated from the crate's published
+ * algorithm (rubato 0.16.2 is not vendored in the reference and cannot be built here): same filter family and
+ * parameters, output n at input time (n+1)/ratio, the last ~129 input samples produce no output.  q3a_load_audio uses it
+ * when the environment has Q3A_RESAMPLER=rubato. */
+int32_t q3a_resample_rubato(const float* in, int64_t n, int32_t sr_in, int32_t sr_out, float** samples_out, int64_t* n_out);
 void q3a_free(void* p);
 
 /* AsrTokenizer (src/tokenizer.rs:4-50) over HuggingFace's tokenizer.json (byte-level BPE). */

@@ -16,7 +16,7 @@ SYMBOLS = [
     "q3a_build_prompt", "q3a_mel", "q3a_encode", "q3a_prefill", "q3a_decode_step", "q3a_set_next_tokens",
     "q3a_upload_pcm", "q3a_run_resident", "q3a_fetch_ids", "q3a_transcribe_batch", "q3a_stage_timings",
     "q3a_profile_decode_step", "q3a_profile_weight_stream", "q3a_debug_read", "q3a_debug_set", "q3a_selftest_gemm", "q3a_selftest_gemm16",
-    "q3a_load_audio", "q3a_resample", "q3a_free", "q3a_tokenizer_create", "q3a_tokenizer_destroy",
+    "q3a_load_audio", "q3a_resample", "q3a_resample_rubato", "q3a_free", "q3a_tokenizer_create", "q3a_tokenizer_destroy",
     "q3a_tokenizer_decode", "q3a_tokenizer_encode", "q3a_parse_asr_output", "q3a_capitalize_first",
 ]
 
@@ -91,6 +91,7 @@ def load() -> C.CDLL:
         "q3a_selftest_gemm16": (i32, [i32, i32, i32, i32, i32, f32p, f32p, f32p, f32p]),
         "q3a_load_audio": (i32, [C.c_char_p, i32, C.POINTER(f32p), i64p]),
         "q3a_resample": (i32, [f32p, i64, i32, i32, C.POINTER(f32p), i64p]),
+        "q3a_resample_rubato": (i32, [f32p, i64, i32, i32, C.POINTER(f32p), i64p]),
         "q3a_free": (None, [P]),
         "q3a_tokenizer_create": (i32, [C.c_char_p, C.POINTER(P)]),
         "q3a_tokenizer_destroy": (None, [P]),

@@ -32,11 +32,14 @@ def load_audio(path: str, target_sr: int = 16000) -> np.ndarray:
     return _take(p, n.value)
 
 
-def resample(x: np.ndarray, sr_in: int, sr_out: int) -> np.ndarray:
+def resample(x: np.ndarray, sr_in: int, sr_out: int, method: str = "polyphase") -> np.ndarray:
+    """method "polyphase": this backend's Kaiser polyphase filter; "rubato": the reference fallback's resampler
+    (src/audio.rs:220-245) restated (see include/q3asr.h q3a_resample_rubato)."""
     lib = _lib.load()
     x = np.ascontiguousarray(x, dtype=np.float32)
     p, n = C.POINTER(C.c_float)(), C.c_int64()
-    if lib.q3a_resample(x.ctypes.data_as(C.POINTER(C.c_float)), len(x), sr_in, sr_out, C.byref(p), C.byref(n)) != 0:
+    fn = lib.q3a_resample_rubato if method == "rubato" else lib.q3a_resample
+    if fn(x.ctypes.data_as(C.POINTER(C.c_float)), len(x), sr_in, sr_out, C.byref(p), C.byref(n)) != 0:
         raise RuntimeError(_err())
     return _take(p, n.value)
 

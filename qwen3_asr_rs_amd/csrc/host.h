@@ -12,6 +12,8 @@ namespace q3a {
 // ---- audio (host_audio.cpp; reference: src/audio.rs) ----
 void read_wav_mono(const std::string& path, std::vector<float>& samples, int& sample_rate);
 void resample_rational(const std::vector<float>& in, int sr_in, int sr_out, std::vector<float>& out);
+// rubato 0.16.2 SincFixedIn with the reference fallback's parameters (src/audio.rs:220-245), restated
+void resample_rubato_sincfixedin(const std::vector<float>& in, int sr_in, int sr_out, std::vector<float>& out);
 std::vector<float> load_audio(const std::string& path, int target_sr);  // audio.rs:7
 
 // ---- tokenizer (host_text.cpp; reference: src/tokenizer.rs over HF tokenizers' tokenizer.json) ----

@@ -63,6 +63,14 @@ int32_t q3a_resample(const float* in, int64_t n, int32_t sr_in, int32_t sr_out, 
   give(o, samples_out, n_out);
   HOST_CATCH
 }
+int32_t q3a_resample_rubato(const float* in, int64_t n, int32_t sr_in, int32_t sr_out, float** samples_out, int64_t* n_out) {
+  HOST_TRY
+  if (!in || n < 0 || sr_in <= 0 || sr_out <= 0) fail("bad argument");
+  std::vector<float> v(in, in + n), o;
+  resample_rubato_sincfixedin(v, sr_in, sr_out, o);
+  give(o, samples_out, n_out);
+  HOST_CATCH
+}
 void q3a_free(void* p) { free(p); }
 
 int32_t q3a_tokenizer_create(const char* path, q3a_tokenizer** out) {

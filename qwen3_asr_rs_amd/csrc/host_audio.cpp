@@ -8,7 +8,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -117,11 +119,74 @@ void resample_rational(const std::vector<float>& in, int sr_in, int sr_out, std:
   }
 }
 
+// The reference's WAV fallback resampler (src/audio.rs:220-245): rubato 0.16.2 `SincFixedIn::<f32>::new(ratio, 2.0,
+// {sinc_len 256, f_cutoff 0.95, Linear, oversampling_factor 256, BlackmanHarris2}, chunk = whole clip, 1 channel)` and ONE
+// `process` call.  rubato is a third-party crate absent from /root/reference (Cargo.lock: rubato 0.16.2); this restates its
+// published algorithm (sinc.rs `make_sincs`, windows.rs `blackman_harris` squared, asynchro_sinc.rs `process_into_buffer`
+// with `InterpolationType::Linear`) in double precision -- it cannot be run against the crate here (no Rust toolchain), so it
+// is "same filter family and parameters", not a bit-level pin:
+//   * table: y[x] = w[x] * sinc((x - T/2) * fc / F), T = 256 * F, F = 256, fc = 0.95 * min(1, ratio), w = squared 4-term
+//     Blackman-Harris over T points; sincs[F-1-n][p] = y[F*p + n] / (sum(y) / F);
+//   * the clip is preceded by 2*256 zeros; idx starts at -128 and advances by 1/ratio BEFORE each output; an output is the
+//     linear interpolation (fraction of idx*F) of the two nearest sub-filters applied to 256 input samples starting at
+//     floor(idx); the loop ends at idx >= n_in - 257.  Output n therefore sits at input time (n+1)/ratio and the last ~129
+//     input samples produce nothing (rubato would deliver them with the next chunk, which the reference never feeds).
+void resample_rubato_sincfixedin(const std::vector<float>& in, int sr_in, int sr_out, std::vector<float>& out) {
+  if (sr_in == sr_out) { out = in; return; }
+  const double ratio = (double)sr_out / (double)sr_in;
+  const int sinc_len = 256, F = 256;
+  const double fc = (ratio >= 1.0) ? 0.95 : 0.95 * (double)(float)ratio;  // rubato scales f_cutoff (an f32) when downsampling
+  const int T = sinc_len * F;
+  const double pi = 3.14159265358979323846;
+  std::vector<double> y((size_t)T);
+  double sum = 0.0;
+  for (int x = 0; x < T; ++x) {
+    const double ph = 2.0 * pi * (double)x / (double)T;
+    double w = 0.35875 - 0.48829 * std::cos(ph) + 0.14128 * std::cos(2.0 * ph) - 0.01168 * std::cos(3.0 * ph);
+    w *= w;  // BlackmanHarris2
+    const double v = ((double)x - (double)(T / 2)) * fc / (double)F;
+    const double sc = (v == 0.0) ? 1.0 : std::sin(pi * v) / (pi * v);
+    y[(size_t)x] = w * sc;
+    sum += y[(size_t)x];
+  }
+  sum /= (double)F;
+  std::vector<float> sincs((size_t)T);  // [sub-filter][tap], stored as f32 like SincFixedIn::<f32>
+  for (int p = 0; p < sinc_len; ++p)
+    for (int n = 0; n < F; ++n) sincs[(size_t)(F - n - 1) * sinc_len + p] = (float)(y[(size_t)F * p + n] / sum);
+  const int64_t n_in = (int64_t)in.size();
+  std::vector<float> buf((size_t)(n_in + 2 * sinc_len), 0.f);
+  std::copy(in.begin(), in.end(), buf.begin() + 2 * sinc_len);
+  const double t_ratio = 1.0 / ratio, end_idx = (double)(n_in - (sinc_len + 1));
+  double idx = -(double)sinc_len / 2.0;
+  out.clear();
+  out.reserve((size_t)((double)n_in * ratio) + 8);
+  auto dot = [&](int64_t index, int64_t sub) {
+    const float* w = &sincs[(size_t)sub * sinc_len];
+    const float* x = &buf[(size_t)(index + 2 * sinc_len)];
+    double acc = 0.0;
+    for (int k = 0; k < sinc_len; ++k) acc += (double)x[k] * (double)w[k];
+    return acc;
+  };
+  while (idx < end_idx) {
+    idx += t_ratio;
+    const double fl = std::floor(idx);
+    int64_t i0 = (int64_t)fl, s0 = (int64_t)std::floor((idx - fl) * (double)F);
+    int64_t i1 = i0, s1 = s0 + 1;
+    if (s1 >= F) { s1 -= F; ++i1; }
+    const double frac = idx * (double)F - std::floor(idx * (double)F);
+    const double p0 = dot(i0, s0), p1 = dot(i1, s1);
+    out.push_back((float)((1.0 - frac) * p0 + frac * p1));
+  }
+}
+
+// $Q3A_RESAMPLER = "rubato": use the reference fallback's resampler (above) instead of this backend's polyphase filter
 std::vector<float> load_audio(const std::string& path, int target_sr) {  // audio.rs:7
   std::vector<float> raw, out;
   int sr = 0;
   read_wav_mono(path, raw, sr);
-  resample_rational(raw, sr, target_sr, out);
+  const char* e = getenv("Q3A_RESAMPLER");
+  if (e && std::string(e) == "rubato") resample_rubato_sincfixedin(raw, sr, target_sr, out);
+  else resample_rational(raw, sr, target_sr, out);
   return out;
 }
 

@@ -87,6 +87,43 @@ def test_resampler_properties(lib):
     assert len(audio.resample(x[:1001], 44100, 16000)) == (1001 * 160 + 440) // 441
 
 
+def test_reference_fallback_resampler_parameters(lib, monkeypatch):
+    """src/audio.rs:220-245: rubato SincFixedIn {sinc_len 256, f_cutoff 0.95, Linear, oversampling 256, BlackmanHarris2}
+    restated (csrc/host_audio.cpp resample_rubato_sincfixedin).  Not a bit-level pin (rubato cannot be built here); what is
+    checked is the published algorithm's observable behaviour: output count (idx from -128 in steps of 1/ratio while
+    idx < n - 257), the sampling grid (output n at input time (n+1)/ratio - 1 + 1/256, i.e. 1.5 n + 0.504 at 24 -> 16 kHz),
+    unit pass-band gain, stop-band rejection, and the residual against this backend's default polyphase filter."""
+    sr_in, sr_out = 24000, 16000
+    n_in = 24000
+    t = np.arange(n_in) / sr_in
+    x = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.25 * np.sin(2 * np.pi * 3000 * t + 0.3)).astype(np.float32)
+    y = audio.resample(x, sr_in, sr_out, "rubato")
+    idx, cnt = -128.0, 0
+    while idx < n_in - 257:
+        idx += 1.5
+        cnt += 1
+    assert len(y) == cnt == 15914
+    to = (1.5 * np.arange(len(y)) + 1.5 - 1.0 + 1.0 / 256) / sr_in       # seconds on the input clock
+    ref = 0.5 * np.sin(2 * np.pi * 440 * to) + 0.25 * np.sin(2 * np.pi * 3000 * to + 0.3)
+    assert np.abs(y[300:-300] - ref[300:-300]).max() < 2e-3
+    alias = audio.resample(np.sin(2 * np.pi * 10000 * t).astype(np.float32), sr_in, sr_out, "rubato")
+    assert np.abs(alias[300:-300]).max() < 2e-3
+    assert np.array_equal(audio.resample(x, sr_in, sr_out, "rubato"), y)
+    # the two resamplers on a reference clip: same pass band, grids 1/3 output sample apart -> compare through the spectrum
+    import wave
+    w = wave.open(os.path.join(GOLDEN, "test_audio", "sample2.wav"))
+    pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768
+    a, b = audio.resample(pcm, 24000, 16000), audio.resample(pcm, 24000, 16000, "rubato")
+    assert len(a) == 66560 and len(b) == len(a) - 86
+    m = 65536
+    fa, fb = np.fft.rfft(a[:m] * np.hanning(m)), np.fft.rfft(b[:m] * np.hanning(m))
+    band = slice(int(100 * m / 16000), int(7000 * m / 16000))
+    assert abs(np.linalg.norm(fb[band]) / np.linalg.norm(fa[band]) - 1.0) < 5e-3        # same magnitude response in the pass band
+    # Q3A_RESAMPLER=rubato switches load_audio (and the CLI) to it
+    monkeypatch.setenv("Q3A_RESAMPLER", "rubato")
+    assert len(audio.load_audio(os.path.join(GOLDEN, "test_audio", "sample2.wav"), 16000)) == len(b)
+
+
 @pytest.fixture(scope="module")
 def bpe_json(tmp_path_factory):
     """A small byte-level BPE tokenizer.json with Qwen2's pre-tokeniser pattern and Qwen-style added tokens,
