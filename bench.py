@@ -256,6 +256,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU legs (configs[2], configs[3])")
     ap.add_argument("--ckpt-dir", default=None)
+    ap.add_argument("--trace-out", default=None, help="write the per-kernel table of the in-situ rocprofv3 kernel trace to this file")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -325,6 +326,14 @@ def main():
             try:
                 trace = kernel_trace(inner + ["--new-tokens", str(args.new_tokens), "--steps", "2", "--warmup", "1"])
                 dom = max(trace.items(), key=lambda kv: kv[1]["total_us"])
+                if args.trace_out:
+                    tot = sum(v["total_us"] for v in trace.values())
+                    with open(args.trace_out, "w") as f:
+                        f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --inner {' '.join(inner)} --new-tokens {args.new_tokens} --steps 2 --warmup 1\n")
+                        f.write(f"# 3 graph-replayed passes of the hot path; total kernel time {tot:.1f} us\n")
+                        f.write(f"{'kernel':96s} {'calls':>7s} {'total_us':>12s} {'avg_us':>9s} {'pct':>6s}\n")
+                        for k, v in sorted(trace.items(), key=lambda kv: -kv[1]["total_us"]):
+                            f.write(f"{k[:96]:96s} {v['calls']:7d} {v['total_us']:12.1f} {v['avg_us']:9.2f} {100 * v['total_us'] / tot:6.2f}\n")
             except Exception as ex:  # noqa: BLE001
                 trace_err = str(ex)[:300]
         roof = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s"}

@@ -507,12 +507,13 @@ struct q3a_engine {
     kcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
     vcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
     rope_cur.ensure((size_t)b * 128 * 4);
-    nn_x.ensure((size_t)32 * H * 2); nn_ss.ensure((size_t)(H / 16) * 32 * 4);
+    const size_t ng = (size_t)n_groups(b);  // groups of <= 32 sequences of the batched decode step
+    nn_x.ensure(ng * 32 * H * 2); nn_ss.ensure(ng * (H / 16) * 32 * 4);
     x_dec.ensure((size_t)b * H * 4); next_tok.ensure((size_t)b * 4); forced_tok.ensure((size_t)b * 4);
     out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
     // s_ctx / s_act also hold the bf16 fragment-order copies of the skinny GEMM path: always 32 sequences there
-    s_ln.ensure((size_t)b * H * 4); s_qkv.ensure((size_t)b * d.qkv_dim() * 4); s_ctx.ensure((size_t)std::max(b, 16) * d.q_dim() * 4);
-    s_act.ensure((size_t)std::max(b, 16) * d.inter * 4); logits.ensure((size_t)b * d.vocab * 4);
+    s_ln.ensure((size_t)b * H * 4); s_qkv.ensure((size_t)b * d.qkv_dim() * 4); s_ctx.ensure(ng * 32 * d.q_dim() * 4);
+    s_act.ensure(ng * 32 * d.inter * 4); logits.ensure((size_t)b * d.vocab * 4);
     part_stride = std::max(128, (d.vocab + 3) / 4);  // >= blocks of the lm_head GEMV at 1 row per wave
     part_val.ensure((size_t)b * part_stride * 4); part_idx.ensure((size_t)b * part_stride * 4);
     attn_nsplit = (max_ctx + dattn_keys_per_split(kv_f32()) - 1) / dattn_keys_per_split(kv_f32());
@@ -629,18 +630,30 @@ struct q3a_engine {
   // Skinny decode path in the default mode: every kernel that writes a row of the residual stream (token embedding,
   // o / down projection) also leaves it pre-normalised for the GEMM that reads it next -- bf16(x * w_norm) in MFMA
   // fragment order in nn_x plus partial sums of x^2 in nn_ss (kernels.h NextNormOut / SkinnyArgs::xw16f).
-  bool prenorm_path() const { return B > kGemvMaxSeq && B <= 32 && !precise(); }
+  bool prenorm_path() const { return B > kGemvMaxSeq && !precise(); }
   int nn_parts() const { return d.hidden / 16; }  // one partial per 16-column block of a hidden-wide GEMM output
+  // Batched decode (more than kGemvMaxSeq sequences) runs in groups of <= 32 sequences: the skinny MFMA GEMM holds 32
+  // sequences per weight sweep, and the second group's sweep of a 4-13 MB matrix is served by the L2 / Infinity Cache.
+  static int n_groups(int b) { return b <= kGemvMaxSeq ? 1 : (b + 31) / 32; }
+  size_t nn_x_stride() const { return (size_t)32 * d.hidden; }         // elements per group
+  size_t nn_ss_stride() const { return (size_t)nn_parts() * 32; }
+  uint16_t* nn_x_g(int g) const { return nn_x.as<uint16_t>() + (size_t)g * nn_x_stride(); }
+  float* nn_ss_g(int g) const { return nn_ss.as<float>() + (size_t)g * nn_ss_stride(); }
+  float* s_ctx_g(int g) const { return s_ctx.as<float>() + (size_t)g * 32 * d.q_dim(); }   // fp32 [S][QD] or bf16 fragment order
+  float* s_act_g(int g) const { return s_act.as<float>() + (size_t)g * 32 * d.inter; }
   NextNormOut first_layer_norm_out() const {
     NextNormOut nn{};
-    if (prenorm_path()) { nn.next_w = wf(L.dec[0].in_ln); nn.next_xw16f = nn_x.as<uint16_t>(); nn.next_ss = nn_ss.as<float>(); nn.nparts = nn_parts(); }
+    if (prenorm_path()) {
+      nn.next_w = wf(L.dec[0].in_ln); nn.next_xw16f = nn_x.as<uint16_t>(); nn.next_ss = nn_ss.as<float>(); nn.nparts = nn_parts();
+      nn.group_stride_x = (long)nn_x_stride(); nn.group_stride_ss = (long)nn_ss_stride();
+    }
     return nn;
   }
 
   // decode-step projection for more than 4 sequences: skinny MFMA GEMM up to 32, generic tiles above
   void batched_proj(const float* x, int ldx, const uint16_t* W, int N, int K, const float* bias, int mode, float* out,
                     int ldo, const float* resid) {
-    const int S = B;
+    const int S = B;  // (precise-mode lm_head only)
     if (S <= 32) {
       SkinnyArgs sk{};
       sk.x = x; sk.ldx = ldx; sk.S = S; sk.W = W; sk.N = N; sk.K = K; sk.bias = bias; sk.mode = mode; sk.out = out; sk.ldo = ldo; sk.resid = resid;
@@ -651,87 +664,97 @@ struct q3a_engine {
     }
   }
 
+  // one decoder layer of the greedy-loop iteration (inference.rs:172-197) for sequences [s0, s0 + S) -- the whole batch on
+  // the GEMV path, one group of <= 32 on the skinny MFMA path
+  void decode_layer(int li, int grp, int s0, int S) {
+    const int H = d.hidden, I = d.inter, QD = d.q_dim(), QKV = d.qkv_dim();
+    const bool qkv_bias = arena_flags & kFlagDecQkvBias, o_bias = arena_flags & kFlagDecOBias, mlp_bias = arena_flags & kFlagDecMlpBias;
+    const bool gemv = B <= kGemvMaxSeq;
+    const DecLayerOff& l = L.dec[li];
+    float* const x = x_dec.as<float>() + (size_t)s0 * H;
+    float* const qkv = s_qkv.as<float>() + (size_t)s0 * QKV;
+    const size_t kv_seq = (size_t)d.n_kv * max_ctx * 128 * kv_elem();  // bytes per sequence and layer
+    DecodeAttnArgs da{};
+    da.qkv = qkv; da.pos = d_pos.as<int>() + s0; da.eps = d.rms_eps;
+    da.rope_cur = rope_cur.as<float>() + (size_t)s0 * 128;
+    da.pm = attn_pm.as<float>() + (size_t)s0 * d.n_q * attn_nsplit; da.pl = attn_pl.as<float>() + (size_t)s0 * d.n_q * attn_nsplit;
+    da.po = attn_po.as<float>() + (size_t)s0 * d.n_q * attn_nsplit * 128; da.nsplit = attn_nsplit;
+    da.n_q = d.n_q; da.n_kv = d.n_kv; da.max_ctx = max_ctx; da.scale_div = sqrtf((float)d.head_dim);
+    da.q_norm = wf(l.q_norm); da.k_norm = wf(l.k_norm);
+    da.kcache = (uint8_t*)kc_layer(li) + (size_t)s0 * kv_seq; da.vcache = (uint8_t*)vc_layer(li) + (size_t)s0 * kv_seq;
+    if (gemv) {
+      GemvArgs g{};
+      g.x = x; g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
+      g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = qkv; g.ldo = QKV;
+      timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, stream)); });
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), stream)); });
+      GemvArgs o{};
+      if (std::min(S, 4) * d.n_q * attn_nsplit <= GEMV_ATTN_MAX_TABLE) {  // merge the key splits inside the o_proj GEMV
+        o.attn_pm = da.pm; o.attn_pl = da.pl; o.attn_po = da.po;
+        o.attn_nsplit = attn_nsplit; o.attn_heads = d.n_q; o.attn_fast_exp = precise() ? 0 : 1;
+      } else {  // very long contexts: separate merge launch
+        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, attn_nsplit, S, d.n_q, s_ctx_g(grp), stream)); });
+        o.x = s_ctx_g(grp);
+      }
+      o.ldx = QD; o.W = wh(l.o_w); o.N = H; o.K = QD; o.bias = o_bias ? wf(l.o_b) : nullptr;
+      o.mode = 1; o.out = x; o.ldo = H; o.resid = x;
+      timed(Q3A_KC_GEMV_O, 2.0 * H * QD, [&] { KCHK(launch_gemv(o, S, stream)); });
+      GemvArgs u{};
+      u.x = x; u.ldx = H; u.rms_w = wf(l.post_ln); u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
+      u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act_g(grp); u.ldo = I;
+      timed(Q3A_KC_GEMV, 4.0 * I * H, [&] { KCHK(launch_gemv(u, S, stream)); });
+      GemvArgs dn{};
+      dn.x = s_act_g(grp); dn.ldx = I; dn.W = wh(l.down_w); dn.N = H; dn.K = I; dn.bias = mlp_bias ? wf(l.down_b) : nullptr;
+      dn.mode = 1; dn.out = x; dn.ldo = H; dn.resid = x;
+      timed(Q3A_KC_GEMV_DOWN, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, stream)); });
+      return;
+    }
+    // skinny MFMA GEMMs: the norms are fused (no norm launches), and in the default mode the two K-heavy projections read
+    // bf16 activations written by their producers (attention, SwiGLU epilogue) in fragment order
+    const bool b16 = !precise(), pre = prenorm_path();
+    SkinnyArgs q{};
+    q.x = x; q.ldx = H; q.S = S; q.eps = d.rms_eps; q.W = wh(l.qkv_w); q.N = QKV; q.K = H;
+    if (pre) { q.xw16f = nn_x_g(grp); q.ss_parts = nn_ss_g(grp); q.ss_nparts = nn_parts(); }
+    else q.rms_w = wf(l.in_ln);
+    q.bias = qkv_bias ? wf(l.qkv_b) : nullptr; q.mode = 0; q.out = qkv; q.ldo = QKV;
+    timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { KCHK(launch_skinny(q, precise(), stream)); });
+    if (g_dattn_batched_min_wgs < 0) { const char* e = getenv("Q3A_DATTN_BATCHED_MIN_WGS"); g_dattn_batched_min_wgs = e ? atoi(e) : 128; }
+    if (S * d.n_kv >= g_dattn_batched_min_wgs) {
+      // the group alone fills the chip: one workgroup per (sequence, kv head) walks all keys and writes the context itself
+      if (b16) { da.out16 = reinterpret_cast<uint16_t*>(s_ctx_g(grp)); da.out_frag = 1; } else da.out = s_ctx_g(grp);
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn_batched(da, S, kv_f32(), stream)); });
+    } else {
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), stream)); });
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, attn_nsplit, S, d.n_q, s_ctx_g(grp), stream, b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr, b16)); });
+    }
+    SkinnyArgs o{};
+    o.x = s_ctx_g(grp); o.x16 = b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr; o.x16_frag = b16; o.ldx = QD; o.S = S; o.W = wh(l.o_w); o.N = H; o.K = QD;
+    o.bias = o_bias ? wf(l.o_b) : nullptr; o.mode = 1; o.out = x; o.ldo = H; o.resid = x;
+    if (pre) { o.next_w = wf(l.post_ln); o.next_xw16f = nn_x_g(grp); o.next_ss = nn_ss_g(grp); }
+    timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { KCHK(launch_skinny(o, precise(), stream)); });
+    SkinnyArgs u{};
+    u.x = x; u.ldx = H; u.S = S; u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
+    if (pre) { u.xw16f = nn_x_g(grp); u.ss_parts = nn_ss_g(grp); u.ss_nparts = nn_parts(); }
+    else u.rms_w = wf(l.post_ln);
+    u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act_g(grp); u.out16 = b16 ? reinterpret_cast<uint16_t*>(s_act_g(grp)) : nullptr; u.out16_frag = b16; u.ldo = I;
+    timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_skinny(u, precise(), stream)); });
+    SkinnyArgs dn{};
+    dn.x = s_act_g(grp); dn.x16 = b16 ? reinterpret_cast<uint16_t*>(s_act_g(grp)) : nullptr; dn.x16_frag = b16; dn.ldx = I; dn.S = S; dn.W = wh(l.down_w); dn.N = H; dn.K = I;
+    dn.bias = mlp_bias ? wf(l.down_b) : nullptr; dn.mode = 1; dn.out = x; dn.ldo = H; dn.resid = x;
+    if (pre && li + 1 < d.dec_layers) {  // (the last layer feeds the final norm + lm_head, which read x_dec)
+      dn.next_w = wf(L.dec[li + 1].in_ln); dn.next_xw16f = nn_x_g(grp); dn.next_ss = nn_ss_g(grp);
+    }
+    timed(Q3A_KC_GEMM, 2.0 * H * I, [&] { KCHK(launch_skinny(dn, precise(), stream)); });
+  }
+
   // one greedy-loop iteration for all sequences (inference.rs:160-200)
   void enqueue_decode_step() {
-    const int S = B, H = d.hidden, I = d.inter, QD = d.q_dim(), QKV = d.qkv_dim();
-    const bool qkv_bias = arena_flags & kFlagDecQkvBias, o_bias = arena_flags & kFlagDecOBias, mlp_bias = arena_flags & kFlagDecMlpBias;
-    const bool gemv = S <= kGemvMaxSeq;
-    DecodeAttnArgs da{};
-    da.qkv = s_qkv.as<float>(); da.pos = d_pos.as<int>(); da.eps = d.rms_eps;
-    da.rope_cur = rope_cur.as<float>();
-    da.pm = attn_pm.as<float>(); da.pl = attn_pl.as<float>(); da.po = attn_po.as<float>(); da.nsplit = attn_nsplit;
-    da.n_q = d.n_q; da.n_kv = d.n_kv; da.max_ctx = max_ctx; da.scale_div = sqrtf((float)d.head_dim);
-    for (int li = 0; li < d.dec_layers; ++li) {
-      const DecLayerOff& l = L.dec[li];
-      if (gemv) {
-        GemvArgs g{};
-        g.x = x_dec.as<float>(); g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
-        g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = s_qkv.as<float>(); g.ldo = QKV;
-        timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, stream)); });
-      } else if (S <= 32) {
-        SkinnyArgs q{};
-        q.x = x_dec.as<float>(); q.ldx = H; q.S = S; q.eps = d.rms_eps; q.W = wh(l.qkv_w); q.N = QKV; q.K = H;
-        if (prenorm_path()) { q.xw16f = nn_x.as<uint16_t>(); q.ss_parts = nn_ss.as<float>(); q.ss_nparts = nn_parts(); }
-        else q.rms_w = wf(l.in_ln);
-        q.bias = qkv_bias ? wf(l.qkv_b) : nullptr; q.mode = 0; q.out = s_qkv.as<float>(); q.ldo = QKV;
-        timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { KCHK(launch_skinny(q, precise(), stream)); });
-      } else {
-        timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(l.in_ln), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
-        timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { batched_proj(s_ln.as<float>(), H, wh(l.qkv_w), QKV, H, qkv_bias ? wf(l.qkv_b) : nullptr, 0, s_qkv.as<float>(), QKV, nullptr); });
+    const int ng = n_groups(B);
+    for (int li = 0; li < d.dec_layers; ++li)
+      for (int g = 0; g < ng; ++g) {
+        const int s0 = ng == 1 ? 0 : g * 32;
+        decode_layer(li, g, s0, ng == 1 ? B : std::min(32, B - s0));
       }
-      da.q_norm = wf(l.q_norm); da.k_norm = wf(l.k_norm); da.kcache = kc_layer(li); da.vcache = vc_layer(li);
-      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), stream)); });
-      if (gemv) {
-        GemvArgs g{};
-        if (std::min(S, 4) * d.n_q * attn_nsplit <= GEMV_ATTN_MAX_TABLE) {  // merge the key splits inside the o_proj GEMV
-          g.attn_pm = attn_pm.as<float>(); g.attn_pl = attn_pl.as<float>(); g.attn_po = attn_po.as<float>();
-          g.attn_nsplit = attn_nsplit; g.attn_heads = d.n_q; g.attn_fast_exp = precise() ? 0 : 1;
-        } else {  // very long contexts: separate merge launch
-          timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream)); });
-          g.x = s_ctx.as<float>();
-        }
-        g.ldx = QD; g.W = wh(l.o_w); g.N = H; g.K = QD; g.bias = o_bias ? wf(l.o_b) : nullptr;
-        g.mode = 1; g.out = x_dec.as<float>(); g.ldo = H; g.resid = x_dec.as<float>();
-        timed(Q3A_KC_GEMV_O, 2.0 * H * QD, [&] { KCHK(launch_gemv(g, S, stream)); });
-        GemvArgs u{};
-        u.x = x_dec.as<float>(); u.ldx = H; u.rms_w = wf(l.post_ln); u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
-        u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act.as<float>(); u.ldo = I;
-        timed(Q3A_KC_GEMV, 4.0 * I * H, [&] { KCHK(launch_gemv(u, S, stream)); });
-        GemvArgs dn{};
-        dn.x = s_act.as<float>(); dn.ldx = I; dn.W = wh(l.down_w); dn.N = H; dn.K = I; dn.bias = mlp_bias ? wf(l.down_b) : nullptr;
-        dn.mode = 1; dn.out = x_dec.as<float>(); dn.ldo = H; dn.resid = x_dec.as<float>();
-        timed(Q3A_KC_GEMV_DOWN, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, stream)); });
-      } else if (S <= 32) {
-        // skinny MFMA GEMMs: the norms are fused (no norm launches), and in the default mode the two K-heavy
-        // projections read bf16 activations written by their producers (attention merge, SwiGLU epilogue)
-        const bool b16 = !precise();
-        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream, b16 ? s_ctx.as<uint16_t>() : nullptr, b16)); });
-        SkinnyArgs o{};
-        o.x = s_ctx.as<float>(); o.x16 = b16 ? s_ctx.as<uint16_t>() : nullptr; o.x16_frag = b16; o.ldx = QD; o.S = S; o.W = wh(l.o_w); o.N = H; o.K = QD;
-        o.bias = o_bias ? wf(l.o_b) : nullptr; o.mode = 1; o.out = x_dec.as<float>(); o.ldo = H; o.resid = x_dec.as<float>();
-        if (prenorm_path()) { o.next_w = wf(l.post_ln); o.next_xw16f = nn_x.as<uint16_t>(); o.next_ss = nn_ss.as<float>(); }
-        timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { KCHK(launch_skinny(o, precise(), stream)); });
-        SkinnyArgs u{};
-        u.x = x_dec.as<float>(); u.ldx = H; u.S = S; u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
-        if (prenorm_path()) { u.xw16f = nn_x.as<uint16_t>(); u.ss_parts = nn_ss.as<float>(); u.ss_nparts = nn_parts(); }
-        else u.rms_w = wf(l.post_ln);
-        u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act.as<float>(); u.out16 = b16 ? s_act.as<uint16_t>() : nullptr; u.out16_frag = b16; u.ldo = I;
-        timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_skinny(u, precise(), stream)); });
-        SkinnyArgs dn{};
-        dn.x = s_act.as<float>(); dn.x16 = b16 ? s_act.as<uint16_t>() : nullptr; dn.x16_frag = b16; dn.ldx = I; dn.S = S; dn.W = wh(l.down_w); dn.N = H; dn.K = I;
-        dn.bias = mlp_bias ? wf(l.down_b) : nullptr; dn.mode = 1; dn.out = x_dec.as<float>(); dn.ldo = H; dn.resid = x_dec.as<float>();
-        if (prenorm_path() && li + 1 < d.dec_layers) {  // (the last layer feeds the final norm + lm_head, which read x_dec)
-          dn.next_w = wf(L.dec[li + 1].in_ln); dn.next_xw16f = nn_x.as<uint16_t>(); dn.next_ss = nn_ss.as<float>();
-        }
-        timed(Q3A_KC_GEMM, 2.0 * H * I, [&] { KCHK(launch_skinny(dn, precise(), stream)); });
-      } else {
-        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(attn_pm.as<float>(), attn_pl.as<float>(), attn_po.as<float>(), attn_nsplit, S, d.n_q, s_ctx.as<float>(), stream)); });
-        timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { batched_proj(s_ctx.as<float>(), QD, wh(l.o_w), H, QD, o_bias ? wf(l.o_b) : nullptr, 1, x_dec.as<float>(), H, x_dec.as<float>()); });
-        timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(l.post_ln), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
-        timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { batched_proj(s_ln.as<float>(), H, wh(l.gu_w), 2 * I, H, mlp_bias ? wf(l.gu_b) : nullptr, 2, s_act.as<float>(), I, nullptr); });
-        timed(Q3A_KC_GEMM, 2.0 * H * I, [&] { batched_proj(s_act.as<float>(), I, wh(l.down_w), H, I, mlp_bias ? wf(l.down_b) : nullptr, 1, x_dec.as<float>(), H, x_dec.as<float>()); });
-      }
-    }
     run_head(1);
   }
 
@@ -1228,6 +1251,7 @@ int32_t q3a_debug_read(q3a_engine* e, const char* name, void* dst, uint64_t byte
 int32_t q3a_debug_set(const char* key, int32_t value) {
   if (!key) return 1;
   if (strcmp(key, "gemm256_min_tiles") == 0) { g_gemm256_min_tiles = value; return 0; }
+  if (strcmp(key, "dattn_batched_min_wgs") == 0) { g_dattn_batched_min_wgs = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";
   return 1;
 }

@@ -237,6 +237,225 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   }
 }
 
+
+// ---- batched form: the batch alone fills the chip (S * n_kv >= ~CUs), so one workgroup walks ALL keys of its
+// (sequence, kv head) in 128-key tiles with an online softmax and writes the normalised context itself.  No partials
+// in HBM, no merge launch (at 32 sequences: 15.4 us attention + 4.8 us merge per layer before).  The tile body is the one
+// above; what changes:
+//   * the next tile's cache rows are requested before the current tile is consumed (register double buffer);
+//   * bf16 cache: q is rounded to bf16 pairs once (the rounding the MFMA prefill attention applies to q as well) and the
+//     scores use v_dot2c_f32_bf16 on the RAW cache dwords: 4 instructions per 8 dims and head instead of 8 unpack
+//     shifts + 4 packed FMAs -- this kernel is VALU-bound at batch 32;
+//   * each wave keeps running (max, sum, acc) over its 16 keys of every tile; the cross-lane / cross-wave folds happen
+//     once at the end.
+template <int GROUP, typename KVT>
+__global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(DecodeAttnArgs a) {
+  constexpr int DPL = Frag16<KVT>::DPL;
+  constexpr int LPK = 128 / DPL;
+  constexpr int KPI = 64 / LPK;
+  constexpr int NI = (128 / DA_WAVES) / KPI;
+  constexpr int KEYS_PER_WAVE = KPI * NI;
+  constexpr bool DOT2 = sizeof(KVT) == 2;
+  __shared__ float q_s[GROUP][128];
+  __shared__ __attribute__((aligned(16))) KVT k_s[128];
+  __shared__ __attribute__((aligned(16))) KVT v_s[128];
+  __shared__ float cm[DA_WAVES][GROUP], cl[DA_WAVES][GROUP];
+  __shared__ float co[DA_WAVES][GROUP][128];
+  const int kvh = blockIdx.x, s = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane % LPK, kq = lane / LPK;
+  const int qkv_dim = (a.n_q + 2 * a.n_kv) * 128;
+  const float* row = a.qkv + (size_t)s * qkv_dim;
+  KVT* kc = reinterpret_cast<KVT*>(a.kcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
+  KVT* vc = reinterpret_cast<KVT*>(a.vcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
+
+  float x1 = 0.f, x2 = 0.f, nw1 = 0.f, nw2 = 0.f, c = 0.f, sn = 0.f;
+  if (wave < GROUP + 2) {  // waves 0..GROUP-1: the q heads, GROUP: k, GROUP+1: v
+    const int r = wave < GROUP ? kvh * GROUP + wave : (wave == GROUP ? a.n_q + kvh : a.n_q + a.n_kv + kvh);
+    x1 = row[r * 128 + lane];
+    x2 = row[r * 128 + lane + 64];
+    if (wave <= GROUP) {
+      const float* nw = wave < GROUP ? a.q_norm : a.k_norm;
+      nw1 = nw[lane];
+      nw2 = nw[lane + 64];
+      c = a.rope_cur[(size_t)s * 128 + lane];
+      sn = a.rope_cur[(size_t)s * 128 + 64 + lane];
+    }
+  }
+  const int key_w = wave * KEYS_PER_WAVE + kq;  // this lane's first key inside a tile
+  uint4 kraw[NI], vraw[NI], kn[NI], vn[NI];
+  auto load_tile = [&](int t, uint4 (&kr)[NI], uint4 (&vr)[NI]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int key = min(t * 128 + key_w + i * KPI, a.max_ctx - 1);  // stale / clamped rows are masked below
+      kr[i] = ld_stream16(kc + (size_t)key * 128 + sub * DPL);
+      vr[i] = ld_stream16(vc + (size_t)key * 128 + sub * DPL);
+    }
+  };
+  load_tile(0, kraw, vraw);
+  __builtin_amdgcn_sched_barrier(0);
+  const int pos = a.pos[s];
+  const int n_tiles = pos / 128 + 1;  // tiles that hold at least one key <= pos
+
+  if (wave <= GROUP) {  // per-head RMSNorm + RoPE (as dev.h head_norm_rope)
+    const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
+    const float rstd = 1.0f / sqrtf(ss / 128.0f + a.eps);
+    const float n1 = (x1 * rstd) * nw1, n2 = (x2 * rstd) * nw2;
+    x1 = n1 * c + (-n2) * sn;
+    x2 = n2 * c + n1 * sn;
+  }
+  if (wave < GROUP) {
+    q_s[wave][lane] = x1;
+    q_s[wave][lane + 64] = x2;
+  } else if (wave == GROUP) {
+    KvIo<KVT>::store(kc + (size_t)pos * 128 + lane, x1);
+    KvIo<KVT>::store(kc + (size_t)pos * 128 + lane + 64, x2);
+    KvIo<KVT>::store(&k_s[lane], x1);
+    KvIo<KVT>::store(&k_s[lane + 64], x2);
+  } else if (wave == GROUP + 1) {
+    KvIo<KVT>::store(vc + (size_t)pos * 128 + lane, x1);
+    KvIo<KVT>::store(vc + (size_t)pos * 128 + lane + 64, x2);
+    KvIo<KVT>::store(&v_s[lane], x1);
+    KvIo<KVT>::store(&v_s[lane + 64], x2);
+  }
+  __syncthreads();
+
+  const float inv_scale = 1.0f / a.scale_div;
+  auto expw = [](float x) { return sizeof(KVT) == 4 ? expf(x) : __expf(x); };
+  f32x2_t qf[GROUP][DPL / 2];
+  uint32_t qp[GROUP][DPL / 2];  // DOT2: q as bf16 pairs
+#pragma unroll
+  for (int g = 0; g < GROUP; ++g)
+#pragma unroll
+    for (int e = 0; e < DPL / 2; ++e) {
+      qf[g][e] = f32x2_t{q_s[g][sub * DPL + 2 * e], q_s[g][sub * DPL + 2 * e + 1]};
+      qp[g][e] = pack_bf16x2(qf[g][e].x, qf[g][e].y);
+    }
+  const uint4 k_new = *reinterpret_cast<const uint4*>(&k_s[sub * DPL]), v_new = *reinterpret_cast<const uint4*>(&v_s[sub * DPL]);
+  f32x2_t acc[GROUP][DPL / 2];
+  float mrun[GROUP], lrun[GROUP];
+#pragma unroll
+  for (int g = 0; g < GROUP; ++g) {
+    mrun[g] = -INFINITY;
+    lrun[g] = 0.f;
+#pragma unroll
+    for (int e = 0; e < DPL / 2; ++e) acc[g][e] = f32x2_t{0.f, 0.f};
+  }
+
+  for (int t = 0; t < n_tiles; ++t) {
+    if (t + 1 < n_tiles) load_tile(t + 1, kn, vn);
+    const int key_base = t * 128 + key_w;
+    float sc[NI][GROUP];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int key = key_base + i * KPI;
+      if (key == pos) { kraw[i] = k_new; vraw[i] = v_new; }
+      if (key > pos) vraw[i] = make_uint4(0u, 0u, 0u, 0u);  // stale cache row (possibly NaN bits): keep 0 * v finite
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g) {
+        float p;
+        if constexpr (DOT2) {
+          const uint32_t kw[4] = {kraw[i].x, kraw[i].y, kraw[i].z, kraw[i].w};
+          p = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            p = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, kw[e]), __builtin_bit_cast(bf16x2_t, qp[g][e]), p, false);
+        } else {
+          float kf[DPL];
+          Frag16<KVT>::unpack(kraw[i], kf);
+          f32x2_t p2 = qf[g][0] * f32x2_t{kf[0], kf[1]};
+#pragma unroll
+          for (int e = 1; e < DPL / 2; ++e) p2 += qf[g][e] * f32x2_t{kf[2 * e], kf[2 * e + 1]};
+          p = p2.x + p2.y;
+        }
+        p = row16_sum(p);
+        if (LPK == 32) p = xor16_sum(p);
+        sc[i][g] = (key <= pos) ? p * inv_scale : -INFINITY;  // layers.rs:327-328 scales after the matmul
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < GROUP; ++g) {
+      float mx = sc[0][g];
+#pragma unroll
+      for (int i = 1; i < NI; ++i) mx = fmaxf(mx, sc[i][g]);
+      if (LPK == 16) mx = xor16_max(mx);
+      mx = xor32_max(mx);  // over the wave's 16 keys of this tile
+      const float m_new = fmaxf(mrun[g], mx);
+      if (m_new == -INFINITY) continue;  // wave-uniform: none of this wave's keys exists yet
+      const float alpha = expw(mrun[g] - m_new);  // exp(-inf) = 0 on the first live tile
+      mrun[g] = m_new;
+      lrun[g] *= alpha;
+#pragma unroll
+      for (int e = 0; e < DPL / 2; ++e) acc[g][e] *= f32x2_t{alpha, alpha};
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int key = key_base + i * KPI;
+      float vf[DPL];
+      Frag16<KVT>::unpack(vraw[i], vf);
+#pragma unroll
+      for (int g = 0; g < GROUP; ++g) {
+        const float p = (key <= pos) ? expw(sc[i][g] - mrun[g]) : 0.f;
+        lrun[g] += p;
+#pragma unroll
+        for (int e = 0; e < DPL / 2; ++e) acc[g][e] += f32x2_t{p, p} * f32x2_t{vf[2 * e], vf[2 * e + 1]};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { kraw[i] = kn[i]; vraw[i] = vn[i]; }
+  }
+  // fold the KPI key columns of the wave (lanes with equal `sub`), then the waves through LDS
+#pragma unroll
+  for (int g = 0; g < GROUP; ++g) {
+    float lw = lrun[g];
+    if (LPK == 16) lw = xor16_sum(lw);
+    lw = xor32_sum(lw);
+    float af[DPL];
+#pragma unroll
+    for (int e = 0; e < DPL; ++e) {
+      af[e] = (e & 1) ? acc[g][e >> 1].y : acc[g][e >> 1].x;
+      if (LPK == 16) af[e] = xor16_sum(af[e]);
+      af[e] = xor32_sum(af[e]);
+    }
+    if (lane == 0) { cm[wave][g] = mrun[g]; cl[wave][g] = lw; }
+    if (kq == 0) {
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) co[wave][g][sub * DPL + e] = af[e];
+    }
+  }
+  __syncthreads();
+  if (wave < GROUP) {
+    const int g = wave;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < DA_WAVES; ++w) M = fmaxf(M, cm[w][g]);  // finite: key 0 <= pos always exists
+    float L = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < DA_WAVES; ++w) {
+      const float f = (cm[w][g] == -INFINITY) ? 0.f : expw(cm[w][g] - M);
+      L += cl[w][g] * f;
+      o0 += co[w][g][lane] * f;
+      o1 += co[w][g][lane + 64] * f;
+    }
+    o0 /= L;
+    o1 /= L;
+    const int head = kvh * GROUP + g;
+    if (a.out16) {
+      const int k0 = head * 128 + lane;
+      if (a.out_frag) {
+        a.out16[skinny_frag_index(s, k0)] = (uint16_t)f32_to_bf16_bits(o0);
+        a.out16[skinny_frag_index(s, k0 + 64)] = (uint16_t)f32_to_bf16_bits(o1);
+      } else {
+        a.out16[(size_t)s * a.n_q * 128 + k0] = (uint16_t)f32_to_bf16_bits(o0);
+        a.out16[(size_t)s * a.n_q * 128 + k0 + 64] = (uint16_t)f32_to_bf16_bits(o1);
+      }
+    } else {
+      a.out[(size_t)s * a.n_q * 128 + head * 128 + lane] = o0;
+      a.out[(size_t)s * a.n_q * 128 + head * 128 + lane + 64] = o1;
+    }
+  }
+}
+
 // merge of the split partials into [S][n_q*128] (only the GEMM decode path needs it as a separate launch)
 __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
                                                            const float* __restrict__ po, int nsplit, float* __restrict__ out,
@@ -278,6 +497,29 @@ const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipS
   else if (group == 4) Q3A_DA(4);
   else return "decode_attn: GQA group must be 1, 2 or 4";
 #undef Q3A_DA
+  return nullptr;
+}
+
+// S * n_kv (= workgroups of the batched kernel) from which the engine's batched decode step uses it; below, the key-split
+// kernel + merge keep more CUs busy.  Environment Q3A_DATTN_BATCHED_MIN_WGS at first use, q3a_debug_set afterwards.
+int g_dattn_batched_min_wgs = -1;
+
+const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s) {
+  if (S <= 0) return nullptr;
+  if (!a.out && !a.out16) return "decode_attn_batched: no output buffer";
+  if (a.out16 && a.out_frag && S > 32) return "decode_attn_batched: fragment order holds at most 32 sequences";
+  const int group = a.n_q / a.n_kv;
+  dim3 grid(a.n_kv, S), block(DA_WAVES * 64);
+#define Q3A_DAB(G)                                                                                          \
+  do {                                                                                                      \
+    if (kv_f32) hipLaunchKernelGGL((decode_attn_batched_kernel<G, float>), grid, block, 0, s, a);          \
+    else hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t>), grid, block, 0, s, a);              \
+  } while (0)
+  if (group == 1) Q3A_DAB(1);
+  else if (group == 2) Q3A_DAB(2);
+  else if (group == 4) Q3A_DAB(4);
+  else return "decode_attn_batched: GQA group must be 1, 2 or 4";
+#undef Q3A_DAB
   return nullptr;
 }
 

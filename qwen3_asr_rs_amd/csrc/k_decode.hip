@@ -37,6 +37,9 @@ __device__ __forceinline__ void embed_row(const uint16_t* __restrict__ embed, in
   const int tid = threadIdx.x, nthr = blockDim.x;
   const uint2* src = reinterpret_cast<const uint2*>(embed + (size_t)id * H);
   float4* dst = reinterpret_cast<float4*>(x_next + (size_t)s * H);
+  const int sl = s & 31;  // position inside its group of 32 sequences (fragment-order buffers hold one group each)
+  uint16_t* const xw = nn.next_xw16f + (size_t)(s >> 5) * nn.group_stride_x;
+  float* const nss = nn.next_ss + (size_t)(s >> 5) * nn.group_stride_ss;
   float ss = 0.f;
   for (int i = tid; i < H / 4; i += nthr) {
     const uint2 v = src[i];
@@ -48,7 +51,7 @@ __device__ __forceinline__ void embed_row(const uint16_t* __restrict__ embed, in
       uint2 pk;  // k = 4i .. 4i+3 are consecutive in fragment order
       pk.x = pack_bf16x2(f.x * w.x, f.y * w.y);
       pk.y = pack_bf16x2(f.z * w.z, f.w * w.w);
-      *reinterpret_cast<uint2*>(nn.next_xw16f + skinny_frag_index(s, 4 * i)) = pk;
+      *reinterpret_cast<uint2*>(xw + skinny_frag_index(sl, 4 * i)) = pk;
     }
   }
   if (nn.next_w) {  // kernel-argument condition: uniform
@@ -58,9 +61,9 @@ __device__ __forceinline__ void embed_row(const uint16_t* __restrict__ embed, in
     if (tid == 0) {
       float t = 0.f;
       for (int w = 0; w < (nthr + 63) / 64; ++w) t += red[w];
-      nn.next_ss[s] = t;
+      nss[sl] = t;
     }
-    for (int p = 1 + tid; p < nn.nparts; p += nthr) nn.next_ss[(size_t)p * 32 + s] = 0.f;
+    for (int p = 1 + tid; p < nn.nparts; p += nthr) nss[(size_t)p * 32 + sl] = 0.f;
   }
 }
 
@@ -184,7 +187,7 @@ const char* launch_embed(const int* ids, int rows, const uint16_t* embed, int H,
 }
 const char* launch_set_tokens(const int* tok, int S, const uint16_t* embed, int H, float* x_next, int* next_tok,
                               hipStream_t s, const NextNormOut& nn) {
-  if (nn.next_w && S > 32) return "set_tokens: the pre-normalised copy holds at most 32 sequences";
+  if (nn.next_w && S > 32 && (nn.group_stride_x <= 0 || nn.group_stride_ss <= 0)) return "set_tokens: more than 32 sequences need group strides";
   hipLaunchKernelGGL(set_tokens_kernel, dim3(S), dim3(256), 0, s, tok, embed, H, x_next, next_tok, nn);
   return nullptr;
 }

@@ -35,6 +35,7 @@ const char* launch_conv3x3s2_gemm16(const uint16_t* X, const uint16_t* zero_page
 // launch_conv3x3s2_gemm16 dispatch to it when gemm256_eligible (enough 256 x 256 tiles, K % 64 == 0, K >= 128)
 bool gemm256_eligible(int M, int N, int K);
 extern int g_gemm256_min_tiles;  // A/B knob, see k_gemm256.hip
+extern int g_dattn_batched_min_wgs;  // A/B knob, see k_dattn.hip: S * n_kv at which the decode step uses launch_decode_attn_batched
 const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
                            bool glu, hipStream_t s);
 const char* launch_conv3x3s2_gemm256(const uint16_t* X, const uint16_t* zero_page, int imgs, int H, int Wd, int C,
@@ -167,6 +168,8 @@ struct NextNormOut {
   uint16_t* next_xw16f;     // [32 * H] fragment order
   float* next_ss;           // [nparts][32]: row 0 receives the row's sum of squares, rows 1..nparts-1 zero
   int nparts;
+  // more than 32 sequences: sequence s belongs to group s / 32, whose buffers start group_stride_* elements further on
+  long group_stride_x, group_stride_ss;
 };
 const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s);
 const char* skinny_init();  // once per device before the first launch_skinny (sets the large-LDS kernel attributes)
@@ -189,10 +192,17 @@ struct DecodeAttnArgs {
   int nsplit;                  // >= ceil(max_ctx / dattn_keys_per_split(kv_f32))
   int n_q, n_kv, max_ctx;
   float scale_div;
+  // launch_decode_attn_batched only: when the batch alone fills the chip (S * n_kv workgroups), one workgroup walks ALL
+  // keys of its (sequence, kv head) and writes the normalised context itself -- no partials, no merge launch:
+  float* out;                  // [S][n_q*128] fp32 (precise mode) ...
+  uint16_t* out16;             // ... or bf16 (default mode), row-major or, with out_frag, in skinny_frag_index order
+  int out_frag;
 };
 constexpr int DATTN_KEYS_PER_SPLIT_BF16 = 128, DATTN_KEYS_PER_SPLIT_F32 = 128;
 inline int dattn_keys_per_split(bool kv_f32) { return kv_f32 ? DATTN_KEYS_PER_SPLIT_F32 : DATTN_KEYS_PER_SPLIT_BF16; }
 const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
+// one workgroup per (sequence, kv head), online softmax over 128-key tiles, final output written directly (a.out / a.out16)
+const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
 // out[S][n_q*128] = merged partials (needed as its own launch only on the GEMM decode path)
 const char* launch_attn_combine(const float* pm, const float* pl, const float* po, int nsplit, int S, int n_q, float* out,
                                 hipStream_t s, uint16_t* out16 = nullptr, bool frag = false);

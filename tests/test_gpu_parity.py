@@ -139,6 +139,26 @@ def test_batch_above_gemv_path(tiny_dir):
     _stage_check(tiny_dir, clips, True, steps=3)
 
 
+def test_batched_decode_attention_and_sequence_groups(tiny_dir):
+    """Batched decode step: (i) the one-workgroup-per-(sequence, kv head) attention kernel (online softmax over 128-key
+    tiles, context written directly, no merge launch) forced on at tiny dims, both modes, long context (7+ tiles);
+    (ii) 40 sequences = a group of 32 + a group of 8 on the skinny MFMA path, each checked against per-utterance oracle
+    runs (teacher-forced logits, exact ids in the precise mode)."""
+    from qwen3_asr_rs_amd import _lib
+    lib = _lib.load()
+    try:
+        assert lib.q3a_debug_set(b"dattn_batched_min_wgs", 1) == 0
+        clips = [synthetic.synthetic_clip(30 + i, 1.2 + 0.41 * i) for i in range(5)] + [synthetic.synthetic_clip(29, 61.3)]
+        _stage_check(tiny_dir, clips, True, steps=3)
+        _stage_check(tiny_dir, clips, False, steps=3)
+        clips = [synthetic.synthetic_clip(40 + i, 1.0 + 0.13 * (i % 9)) for i in range(40)]
+        _stage_check(tiny_dir, clips, True, steps=3)
+        assert lib.q3a_debug_set(b"dattn_batched_min_wgs", 1 << 30) == 0   # key splits + merge on the same groups
+        _stage_check(tiny_dir, clips[:35], False, steps=3)
+    finally:
+        lib.q3a_debug_set(b"dattn_batched_min_wgs", 128)
+
+
 def test_mfma_attention_matches_valu_attention(tiny_dir):
     """Default mode: the MFMA flash-attention kernels against the fp32 VALU kernels on the same inputs
     (two windows in the encoder, ragged causal prefill)."""
