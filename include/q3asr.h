@@ -132,6 +132,27 @@ int32_t q3a_transcribe_batch(q3a_engine* e, const float* pcm16k, const int64_t* 
                              const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new,
                              int32_t fixed_new_tokens, int32_t* out_ids, int32_t stride, int32_t* out_lens);
 
+/* ---- multi-GPU: one process, one host thread per GPU ------------------------------------ */
+/* The reference is single-device (src/main.rs:51-65 picks ONE device); a batch of independent utterances is new
+ * functionality whose result equals running AsrInference::transcribe (src/inference.rs:89) once per utterance. */
+typedef struct q3a_group q3a_group;
+/* Load once, replicate to n_gpus GPUs: the checkpoint is read and packed on the host ONCE, uploaded to devices[0] and
+ * shipped to the other GPUs with ONE ncclBroadcast of the whole weight arena over xGMI (RCCL, ncclCommInitAll; librccl is
+ * dlopen'ed here).  devices == NULL means 0..n_gpus-1.  Every GPU then owns a q3a_engine created from its copy. */
+int32_t q3a_group_create(const char* model_dir, int32_t n_gpus, const int32_t* devices, const q3a_opts* opts, q3a_group** out);
+void q3a_group_destroy(q3a_group* g);
+int32_t q3a_group_size(const q3a_group* g);
+int32_t q3a_group_used_rccl(const q3a_group* g);  /* 1 when the arena went through ncclBroadcast */
+const char* q3a_group_last_error(const q3a_group* g);
+q3a_engine* q3a_group_engine(q3a_group* g, int32_t rank);  /* borrowed handle of rank's engine (stage API, timings) */
+/* Static contiguous split of n_items utterances: rank gets [*begin, *end) (the first n_items % world_size ranks one more). */
+void q3a_group_partition(int32_t n_items, int32_t world_size, int32_t rank, int32_t* begin, int32_t* end);
+/* q3a_transcribe_batch over the group: utterances are partitioned with q3a_group_partition, every GPU runs its slice from
+ * its own host thread, results land in the caller's arrays in utterance order.  No collective on the data path. */
+int32_t q3a_group_transcribe(q3a_group* g, const float* pcm16k, const int64_t* n_samples, int32_t B,
+                             const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new, int32_t fixed_new_tokens,
+                             int32_t* out_ids, int32_t stride, int32_t* out_lens);
+
 /* ---- measurement ---------------------------------------------------------------------------------- */
 
 typedef struct q3a_timings {

@@ -204,6 +204,57 @@ class HipEngine:
         return out
 
 
+class HipGroup:
+    """q3a_group: one process, one host thread per GPU; weights loaded once and replicated with one RCCL broadcast;
+    utterances partitioned contiguously (include/q3asr.h, csrc/group.cpp)."""
+
+    def __init__(self, model_dir: str, n_gpus: int = 1, devices: Optional[Sequence[int]] = None, precise: bool = False,
+                 max_new_tokens: int = 4096):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        opts = _lib.Opts()
+        self._lib.q3a_opts_default(C.byref(opts))
+        opts.precise = int(precise)
+        opts.max_new_tokens = int(max_new_tokens)
+        dv = np.asarray(devices, dtype=np.int32) if devices is not None else None
+        rc = self._lib.q3a_group_create(os.fsencode(model_dir), n_gpus, _i32p(dv) if dv is not None else None, C.byref(opts), C.byref(self._h))
+        if rc != 0:
+            raise Q3aError((self._lib.q3a_last_error(None) or b"").decode())
+
+    @property
+    def size(self) -> int:
+        return int(self._lib.q3a_group_size(self._h))
+
+    @property
+    def used_rccl(self) -> bool:
+        return bool(self._lib.q3a_group_used_rccl(self._h))
+
+    def transcribe_batch(self, clips: Sequence[np.ndarray], lang_prefix_ids: Optional[Sequence[int]] = None,
+                         max_new: int = 4096, fixed_new_tokens: int = 0) -> List[List[int]]:
+        pcm, ns = HipEngine._concat(clips)
+        B = len(clips)
+        stride = fixed_new_tokens if fixed_new_tokens > 0 else max_new
+        out = np.zeros((B, stride), dtype=np.int32)
+        lens = np.zeros(B, dtype=np.int32)
+        pre = np.asarray(lang_prefix_ids if lang_prefix_ids is not None else [], dtype=np.int32)
+        rc = self._lib.q3a_group_transcribe(self._h, _f32p(pcm), _i64p(ns), B, _i32p(pre) if len(pre) else None, len(pre), max_new,
+                                            fixed_new_tokens, _i32p(out), stride, _i32p(lens))
+        if rc != 0:
+            raise Q3aError((self._lib.q3a_group_last_error(self._h) or b"").decode())
+        return [out[b, :min(int(lens[b]), stride)].tolist() for b in range(B)]
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.q3a_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def selftest_gemm16(M: int, N: int, K: int, reps: int = 0, device: int = 0) -> dict:
     """bf16-activation GEMM (global_load_lds path) vs the naive device reference; optional timing of both GEMMs."""
     lib = _lib.load()

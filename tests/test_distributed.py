@@ -66,3 +66,28 @@ def test_arena_broadcast_and_gather_world2(tiny_dir, lib):
     assert s0 == (0, 3) and s1 == (3, 5)
     expect = [[100 * i + k for k in range(i + 1)] for i in range(5)]
     assert ids0 == expect and ids1 == expect
+
+
+def test_native_group_partition_matches_python(lib):
+    """q3a_group_partition (csrc/group.cpp) is the split q3a_group_transcribe uses: identical to distributed.partition."""
+    import ctypes as C
+    from qwen3_asr_rs_amd.distributed import partition
+    for n in (1, 2, 5, 32, 33, 256, 257):
+        for w in (1, 2, 3, 8):
+            covered = []
+            for r in range(w):
+                b, e = C.c_int32(), C.c_int32()
+                lib.q3a_group_partition(n, w, r, C.byref(b), C.byref(e))
+                assert (b.value, e.value) == partition(n, w, r)
+                covered += list(range(b.value, e.value))
+            assert covered == list(range(n))
+
+
+def test_native_group_fails_loudly_without_gpu(lib, tiny_dir):
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    assert lib.q3a_group_create(tiny_dir.encode(), 2, None, None, C.byref(h)) != 0
+    assert b"no HIP device" in lib.q3a_last_error(None)

@@ -235,6 +235,28 @@ def test_replica_from_broadcast_arena(tiny_dir):
         HipEngine(tiny_dir, 0, device_arena=(arena.data_ptr(), arena.numel() - 256))
 
 
+def test_native_group_one_gpu_through_rccl(tiny_dir, monkeypatch):
+    """q3a_group_create / q3a_group_transcribe (csrc/group.cpp) on the one GPU of this box: Q3A_GROUP_FORCE_RCCL=1 makes the
+    start-up go through librccl (dlopen, ncclCommInitAll with one rank, ncclBroadcast of the arena, destroy) exactly as the
+    n-GPU path does; the group's ids must equal the single-engine ids, utterance by utterance."""
+    from qwen3_asr_rs_amd.engine import HipGroup, Q3aError
+    clips = [synthetic.synthetic_clip(50 + i, 1.0 + 0.3 * i) for i in range(3)]
+    eng = HipEngine(tiny_dir, 0, max_new_tokens=8)
+    ref = eng.transcribe_batch(clips, None, max_new=5, fixed_new_tokens=5)
+    eng.close()
+    monkeypatch.setenv("Q3A_GROUP_FORCE_RCCL", "1")
+    grp = HipGroup(tiny_dir, 1, max_new_tokens=8)
+    assert grp.size == 1 and grp.used_rccl
+    assert grp.transcribe_batch(clips, None, max_new=5, fixed_new_tokens=5) == ref
+    grp.close()
+    monkeypatch.delenv("Q3A_GROUP_FORCE_RCCL")
+    grp = HipGroup(tiny_dir, 1, max_new_tokens=8)
+    assert not grp.used_rccl and grp.transcribe_batch(clips[:1], None, max_new=5, fixed_new_tokens=5) == ref[:1]
+    grp.close()
+    with pytest.raises(Q3aError, match="out of range"):
+        HipGroup(tiny_dir, 64)
+
+
 def test_long_audio_many_windows_and_long_context(tiny_dir):
     """61.3 s clip: 62 chunks -> 8 attention windows in the encoder, prompt of ~800 tokens -> the decode step
     runs over 7+ key splits (flash-decoding merge in the o_proj GEMV); plus an exact multiple of the chunk size."""
