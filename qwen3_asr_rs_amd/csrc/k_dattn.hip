@@ -283,7 +283,11 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
     }
   }
   const int key_w = wave * KEYS_PER_WAVE + kq;  // this lane's first key inside a tile
-  uint4 kraw[NI], vraw[NI], kn[NI], vn[NI];
+  // Register ring of RING tiles: the rows of tiles t+1 .. t+RING-1 are in flight while tile t is consumed (one CU must
+  // keep > 100 KB requested to stream its share of HBM bandwidth; with one tile ahead the loop ran at one memory round
+  // trip per 128 keys: 15.3 us per layer at 32 sequences x 500 keys against ~10 us of HBM time)
+  constexpr int RING = DOT2 ? 3 : 1;  // (the fp32 cache of the precise mode has twice the registers per tile: no ring there)
+  uint4 kr0[NI], vr0[NI], kr1[RING > 1 ? NI : 1], vr1[RING > 1 ? NI : 1], kr2[RING > 1 ? NI : 1], vr2[RING > 1 ? NI : 1];
   auto load_tile = [&](int t, uint4 (&kr)[NI], uint4 (&vr)[NI]) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -292,7 +296,11 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
       vr[i] = ld_stream16(vc + (size_t)key * 128 + sub * DPL);
     }
   };
-  load_tile(0, kraw, vraw);
+  load_tile(0, kr0, vr0);
+  if constexpr (RING > 1) {
+    load_tile(1, kr1, vr1);  // unconditional (clamped): nothing here waits for `pos`
+    load_tile(2, kr2, vr2);
+  }
   __builtin_amdgcn_sched_barrier(0);
   const int pos = a.pos[s];
   const int n_tiles = pos / 128 + 1;  // tiles that hold at least one key <= pos
@@ -342,8 +350,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
     for (int e = 0; e < DPL / 2; ++e) acc[g][e] = f32x2_t{0.f, 0.f};
   }
 
-  for (int t = 0; t < n_tiles; ++t) {
-    if (t + 1 < n_tiles) load_tile(t + 1, kn, vn);
+  auto consume = [&](int t, uint4 (&kraw)[NI], uint4 (&vraw)[NI]) {
     const int key_base = t * 128 + key_w;
     float sc[NI][GROUP];
 #pragma unroll
@@ -401,8 +408,20 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
         for (int e = 0; e < DPL / 2; ++e) acc[g][e] += f32x2_t{p, p} * f32x2_t{vf[2 * e], vf[2 * e + 1]};
       }
     }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) { kraw[i] = kn[i]; vraw[i] = vn[i]; }
+  };
+  for (int t = 0; t < n_tiles; t += RING) {
+    consume(t, kr0, vr0);
+    if (t + RING < n_tiles) load_tile(t + RING, kr0, vr0);
+    if constexpr (RING > 1) {
+      if (t + 1 < n_tiles) {
+        consume(t + 1, kr1, vr1);
+        if (t + 1 + RING < n_tiles) load_tile(t + 1 + RING, kr1, vr1);
+      }
+      if (t + 2 < n_tiles) {
+        consume(t + 2, kr2, vr2);
+        if (t + 2 + RING < n_tiles) load_tile(t + 2 + RING, kr2, vr2);
+      }
+    }
   }
   // fold the KPI key columns of the wave (lanes with equal `sub`), then the waves through LDS
 #pragma unroll
