@@ -248,6 +248,9 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
 //     shifts + 4 packed FMAs -- this kernel is VALU-bound at batch 32;
 //   * each wave keeps running (max, sum, acc) over its 16 keys of every tile; the cross-lane / cross-wave folds happen
 //     once at the end.
+#ifndef Q3A_DATTN_RING
+#define Q3A_DATTN_RING 2  // tiles in flight per wave (A/B: 2 = one tile ahead 15.3 us per layer at 32 x 500 keys, 3 = 16.6 us)
+#endif
 template <int GROUP, typename KVT>
 __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(DecodeAttnArgs a) {
   constexpr int DPL = Frag16<KVT>::DPL;
@@ -286,8 +289,9 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   // Register ring of RING tiles: the rows of tiles t+1 .. t+RING-1 are in flight while tile t is consumed (one CU must
   // keep > 100 KB requested to stream its share of HBM bandwidth; with one tile ahead the loop ran at one memory round
   // trip per 128 keys: 15.3 us per layer at 32 sequences x 500 keys against ~10 us of HBM time)
-  constexpr int RING = DOT2 ? 3 : 1;  // (the fp32 cache of the precise mode has twice the registers per tile: no ring there)
-  uint4 kr0[NI], vr0[NI], kr1[RING > 1 ? NI : 1], vr1[RING > 1 ? NI : 1], kr2[RING > 1 ? NI : 1], vr2[RING > 1 ? NI : 1];
+  constexpr int RING = DOT2 ? Q3A_DATTN_RING : 1;  // (the fp32 cache of the precise mode has twice the registers per tile: no ring there)
+  static_assert(RING >= 1 && RING <= 3, "ring depth");
+  uint4 kr0[NI], vr0[NI], kr1[RING > 1 ? NI : 1], vr1[RING > 1 ? NI : 1], kr2[RING > 2 ? NI : 1], vr2[RING > 2 ? NI : 1];
   auto load_tile = [&](int t, uint4 (&kr)[NI], uint4 (&vr)[NI]) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -297,10 +301,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
     }
   };
   load_tile(0, kr0, vr0);
-  if constexpr (RING > 1) {
-    load_tile(1, kr1, vr1);  // unconditional (clamped): nothing here waits for `pos`
-    load_tile(2, kr2, vr2);
-  }
+  if constexpr (RING > 1) load_tile(1, kr1, vr1);  // unconditional (clamped): nothing here waits for `pos`
+  if constexpr (RING > 2) load_tile(2, kr2, vr2);
   __builtin_amdgcn_sched_barrier(0);
   const int pos = a.pos[s];
   const int n_tiles = pos / 128 + 1;  // tiles that hold at least one key <= pos
@@ -417,6 +419,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
         consume(t + 1, kr1, vr1);
         if (t + 1 + RING < n_tiles) load_tile(t + 1 + RING, kr1, vr1);
       }
+    }
+    if constexpr (RING > 2) {
       if (t + 2 < n_tiles) {
         consume(t + 2, kr2, vr2);
         if (t + 2 + RING < n_tiles) load_tile(t + 2 + RING, kr2, vr2);
