@@ -70,6 +70,10 @@ void q3a_engine_destroy(q3a_engine* e);
 /* Last error of `e` (or of the calling thread when e == NULL, e.g. after a failed create). */
 const char* q3a_last_error(const q3a_engine* e);
 int32_t q3a_get_dims(const q3a_engine* e, q3a_dims* out);
+/* 1 when the checkpoint held F16 / F32 matrices: the arena stores every matrix as bf16, so those were rounded to nearest-even
+ * (the reference widens them to f32 instead, src/weights.rs:74-89,134-181).  0 for the published BF16 checkpoints, whose
+ * bf16 -> f32 widening is exact: arena storage is lossless there.  Vectors (norm weights, biases, conv1) are kept in f32. */
+int32_t q3a_weights_rounded(const q3a_engine* e);
 
 /* ---- shape helpers (host integer arithmetic) --------------------------------------------------------- */
 /* mel frames for n samples: ceil(n/160) (src/mel.rs:51,83-84). */

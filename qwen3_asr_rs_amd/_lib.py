@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("Q3A_LIB") or os.path.join(HERE, "lib", "libq3asr_hip.
 # every symbol include/q3asr.h declares (tests check the exports against the header text)
 SYMBOLS = [
     "q3a_opts_default", "q3a_engine_create", "q3a_arena_bytes", "q3a_arena_pack", "q3a_engine_create_from_arena",
-    "q3a_engine_destroy", "q3a_last_error", "q3a_get_dims", "q3a_num_frames", "q3a_num_audio_tokens",
+    "q3a_engine_destroy", "q3a_last_error", "q3a_get_dims", "q3a_weights_rounded", "q3a_num_frames", "q3a_num_audio_tokens",
     "q3a_build_prompt", "q3a_mel", "q3a_encode", "q3a_prefill", "q3a_decode_step", "q3a_set_next_tokens",
     "q3a_upload_pcm", "q3a_run_resident", "q3a_fetch_ids", "q3a_transcribe_batch", "q3a_stage_timings",
     "q3a_profile_decode_step", "q3a_profile_weight_stream", "q3a_debug_read", "q3a_debug_set", "q3a_selftest_gemm", "q3a_selftest_gemm16",
@@ -72,6 +72,7 @@ def load() -> C.CDLL:
         "q3a_engine_destroy": (None, [P]),
         "q3a_last_error": (C.c_char_p, [P]),
         "q3a_get_dims": (i32, [P, C.POINTER(DimsC)]),
+        "q3a_weights_rounded": (i32, [P]),
         "q3a_num_frames": (i64, [i64]),
         "q3a_num_audio_tokens": (i32, [P, i64]),
         "q3a_build_prompt": (i32, [i32, i32p, i32, i32p, i32p]),

@@ -51,6 +51,8 @@ int main(int argc, char** argv) {
   q3a_opts_default(&opts);
   q3a_engine* eng = nullptr;
   if (q3a_engine_create(model_path, 0, &opts, &eng) != 0) return die(std::string("Failed to load model: ") + q3a_last_error(nullptr));
+  if (q3a_weights_rounded(eng))
+    logf(0, "warning: the checkpoint stores F16/F32 matrices; the HIP backend keeps matrices as bf16 (rounded to nearest-even)");
   logf(1, "Loading tokenizer...");
   q3a_tokenizer* tok = nullptr;
   const std::string tj = std::string(model_path) + "/tokenizer.json";

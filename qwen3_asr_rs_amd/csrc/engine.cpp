@@ -992,6 +992,8 @@ int32_t q3a_get_dims(const q3a_engine* e, q3a_dims* o) {
   return 0;
 }
 
+int32_t q3a_weights_rounded(const q3a_engine* e) { return e && (e->arena_flags & kFlagWeightsRounded) ? 1 : 0; }
+
 int64_t q3a_num_frames(int64_t n_samples) { return (n_samples + 159) / 160; }
 int32_t q3a_num_audio_tokens(const q3a_engine* e, int64_t n_frames) { return e ? e->d.audio_tokens(n_frames) : -1; }
 

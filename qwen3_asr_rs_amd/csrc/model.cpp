@@ -214,8 +214,10 @@ static inline float elem_f32(const TensorView& t, int64_t i) {
     default: fail("integer tensor where a float tensor is expected");
   }
 }
+static thread_local bool g_rounded_weights = false;  // set when a non-bf16 matrix element passes through elem_bf16 (pack_arena reads it)
 static inline uint16_t elem_bf16(const TensorView& t, int64_t i) {
   if (t.dtype == StDtype::BF16) return ((const uint16_t*)t.data)[i];
+  g_rounded_weights = true;
   return f32_to_bf16(elem_f32(t, i));
 }
 
@@ -315,6 +317,7 @@ static void put_bf16_rows(uint8_t* dst, uint64_t off, int64_t row0, const Tensor
 }
 
 void pack_arena(const Dims& d, const ArenaLayout& L, const Checkpoint& ck, uint8_t* dst) {
+  g_rounded_weights = false;
   memset(dst, 0, kArenaHeaderBytes);
   ArenaHeader hdr;
   memset(&hdr, 0, sizeof(hdr));
@@ -441,6 +444,7 @@ void pack_arena(const Dims& d, const ArenaLayout& L, const Checkpoint& ck, uint8
     }
   }
   put_f32(dst, L.final_norm, ck.get(tm + ".norm.weight"), H, tm + ".norm.weight");  // text_decoder.rs:69
+  if (g_rounded_weights) hdr.flags |= kFlagWeightsRounded;
   memcpy(dst, &hdr, sizeof(hdr));
 }
 

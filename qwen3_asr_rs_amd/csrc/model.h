@@ -95,6 +95,9 @@ enum ArenaFlags : uint32_t {
   kFlagDecQkvBias = 1u << 1,
   kFlagDecOBias = 1u << 2,
   kFlagDecMlpBias = 1u << 3,
+  // at least one matrix tensor of the checkpoint was F16 / F32 and has been rounded (nearest-even) to the arena's bf16:
+  // the reference widens such checkpoints to f32 instead (weights.rs:74-89), so results may differ beyond bf16-checkpoint parity
+  kFlagWeightsRounded = 1u << 4,
 };
 struct ArenaHeader {
   uint32_t magic, version;

@@ -110,12 +110,18 @@ def _gen_tensor(shape, kind, scale, gen: torch.Generator) -> torch.Tensor:
     return v.reshape(shape).to(torch.bfloat16)
 
 
-def _write_safetensors(path: str, tensors: List[Tuple[str, torch.Tensor]]):
+_ST_DTYPES = {"BF16": (torch.bfloat16, torch.int16, 2), "F16": (torch.float16, torch.int16, 2), "F32": (torch.float32, torch.int32, 4)}
+
+
+def _write_safetensors(path: str, tensors: List[Tuple[str, torch.Tensor]], dtype: str = "BF16"):
+    """dtype: storage type of every tensor (the published checkpoints are BF16; F16 / F32 exercise the widening paths of
+    src/weights.rs:74-89,134-181)."""
+    tdt, idt, esz = _ST_DTYPES[dtype]
     header: Dict[str, dict] = {}
     off = 0
     for name, t in tensors:
-        nbytes = t.numel() * 2
-        header[name] = {"dtype": "BF16", "shape": list(t.shape), "data_offsets": [off, off + nbytes]}
+        nbytes = t.numel() * esz
+        header[name] = {"dtype": dtype, "shape": list(t.shape), "data_offsets": [off, off + nbytes]}
         off += nbytes
     hj = json.dumps(header, separators=(",", ":")).encode("utf-8")
     hj += b" " * ((8 - len(hj) % 8) % 8)
@@ -123,17 +129,17 @@ def _write_safetensors(path: str, tensors: List[Tuple[str, torch.Tensor]]):
         f.write(struct.pack("<Q", len(hj)))
         f.write(hj)
         for _, t in tensors:
-            f.write(t.contiguous().view(torch.int16).numpy().tobytes())
+            f.write(t.to(tdt).contiguous().view(idt).numpy().tobytes())
 
 
 def write_checkpoint(model_dir: str, preset: str = "tiny", seed: int = 0, shards: int = 1,
-                     cfg: Optional[dict] = None, eos_trap: bool = False) -> str:
+                     cfg: Optional[dict] = None, eos_trap: bool = False, dtype: str = "BF16") -> str:
     """Write config.json + model.safetensors (or `shards` shard files + index json, exercising
     the sharded path of src/weights.rs:29-58).  Idempotent: a finished directory is reused.
     eos_trap (untied lm_head only): column 0 of the lm_head is zeroed except +/-64 on the two EOS rows,
     so every argmax is an EOS token -- exercises the stop condition of src/inference.rs:163-165."""
     cfg = cfg or PRESETS[preset]
-    tag = hashlib.sha1(json.dumps([cfg, seed, shards, eos_trap], sort_keys=True).encode()).hexdigest()[:12]
+    tag = hashlib.sha1(json.dumps([cfg, seed, shards, eos_trap] + ([dtype] if dtype != "BF16" else []), sort_keys=True).encode()).hexdigest()[:12]
     done = os.path.join(model_dir, f".complete.{tag}")
     if os.path.exists(done):
         return model_dir
@@ -151,14 +157,14 @@ def write_checkpoint(model_dir: str, preset: str = "tiny", seed: int = 0, shards
                 t[151643, 0] = 64.0
                 t[151645, 0] = -64.0
     if shards <= 1:
-        _write_safetensors(os.path.join(model_dir, "model.safetensors"), tensors)
+        _write_safetensors(os.path.join(model_dir, "model.safetensors"), tensors, dtype)
     else:
         per = (len(tensors) + shards - 1) // shards
         wm = {}
         for si in range(shards):
             name = f"model-{si + 1:05d}-of-{shards:05d}.safetensors"
             part = tensors[si * per:(si + 1) * per]
-            _write_safetensors(os.path.join(model_dir, name), part)
+            _write_safetensors(os.path.join(model_dir, name), part, dtype)
             for k, _ in part:
                 wm[k] = name
         with open(os.path.join(model_dir, "model.safetensors.index.json"), "w") as f:

@@ -81,6 +81,42 @@ def test_sharded_and_untied_checkpoint_packs(lib, tiny_untied_dir):
     assert s.find(_bf16(w["thinker.model.embed_tokens.weight"][:32]).tobytes()) >= 0
 
 
+def test_f16_and_f32_checkpoints_pack_like_bf16_and_round_to_nearest_even(lib, tmp_path):
+    """weights.rs:74-89,134-181 widen F16 / BF16 / F32 to f32.  The arena stores matrices as bf16: (i) a checkpoint whose F16 /
+    F32 tensors hold bf16-representable values packs to exactly the bytes of the BF16 checkpoint (lossless); (ii) values
+    with more mantissa are rounded to nearest-even -- torch's own float -> bfloat16 conversion -- and the arena header
+    carries the weights-rounded flag (include/q3asr.h q3a_weights_rounded); vectors stay f32 (exact)."""
+    flags_of = lambda arena: int(arena[:32].view(np.uint32)[4])
+    base = _arena(lib, synthetic.write_checkpoint(str(tmp_path / "bf16"), "tiny", seed=7))
+    assert not flags_of(base) & (1 << 4)
+    for dt in ("F16", "F32"):
+        d = synthetic.write_checkpoint(str(tmp_path / dt), "tiny", seed=7, dtype=dt)
+        assert O.load_model_weights(d)["thinker.model.norm.weight"].dtype == torch.float32   # the oracle widens as the reference does
+        got = _arena(lib, d)
+        assert flags_of(got) & (1 << 4), dt                # the checkpoint held non-bf16 matrices
+        if dt == "F32":                                    # every bf16 value is an f32 value: same bytes after the header
+            assert np.array_equal(got[256:], base[256:])
+        else:                                              # f16 loses the small magnitudes of bf16: arena = bf16(widened f16), nearest-even
+            want = _bf16(O.load_model_weights(d)["thinker.model.layers.1.mlp.down_proj.weight"].flatten())
+            hay = got.view(np.uint16)
+            starts = np.flatnonzero(hay[:len(hay) - len(want) + 1] == want[0])
+            assert any(np.array_equal(hay[i:i + len(want)], want) for i in starts)
+    # a genuinely finer F32 checkpoint: one matrix rewritten with full-mantissa values
+    d = synthetic.write_checkpoint(str(tmp_path / "fine"), "tiny", seed=8, dtype="F32")
+    path = os.path.join(d, "model.safetensors")
+    raw = bytearray(open(path, "rb").read())
+    hlen = struct.unpack("<Q", raw[:8])[0]
+    lo, hi = json.loads(raw[8:8 + hlen])["thinker.model.layers.0.mlp.down_proj.weight"]["data_offsets"]
+    fine = torch.randn((hi - lo) // 4, generator=torch.Generator().manual_seed(3)) * 0.05
+    raw[8 + hlen + lo:8 + hlen + hi] = fine.numpy().tobytes()
+    open(path, "wb").write(raw)
+    hay = _arena(lib, d).view(np.uint16)
+    want = _bf16(fine)                                      # torch float -> bfloat16 is round-to-nearest-even
+    assert not np.array_equal(want, (fine.view(torch.int32) >> 16).to(torch.int16).numpy().view(np.uint16))   # (truncation would differ)
+    starts = np.flatnonzero(hay[:len(hay) - len(want) + 1] == want[0])
+    assert any(np.array_equal(hay[i:i + len(want)], want) for i in starts), "nearest-even rounded down_proj matrix not found in the arena"
+
+
 def test_missing_weight_reports_key(lib, tmp_path):
     d = synthetic.write_checkpoint(str(tmp_path / "m"), "tiny", seed=3)
     # drop one tensor from the safetensors header
