@@ -24,7 +24,7 @@ CLI_PATH = os.path.join(BIN_DIR, "asr")  # the reference's CLI (src/main.rs) on 
 
 SOURCES = ["engine.cpp", "model.cpp", "k_gemm.hip", "k_mel.hip", "k_conv1.hip", "k_norm.hip", "k_attn.hip", "k_decode.hip", "k_gemv.hip", "k_dattn.hip", "k_fattn.hip", "k_skinny.hip", "k_gemm16.hip", "k_gemm256.hip",
            "host_audio.cpp", "host_text.cpp", "host_abi.cpp", "group.cpp", "ops.cpp", "k_ops.hip"]
-HEADERS = ["dev.h", "kernels.h", "model.h", "json.h", "host.h", "ops.h", os.path.join("..", "..", "include", "q3asr.h"),
+HEADERS = ["dev.h", "kernels.h", "model.h", "json.h", "host.h", "ops.h", "unicode_tables.h", os.path.join("..", "..", "include", "q3asr.h"),
            os.path.join("..", "..", "include", "q3asr_ops.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]

@@ -21,8 +21,9 @@ class BpeTokenizer {
  public:
   explicit BpeTokenizer(const std::string& tokenizer_json_path);      // tokenizer.rs:11-30
   std::string decode(const std::vector<int64_t>& ids, bool skip_special = true) const;  // tokenizer.rs:42-49
-  // Byte-level BPE encode of text made of ASCII letters/digits/spaces/punctuation ("language English"):
-  // GPT-2 style pre-tokenisation restricted to that alphabet; throws on other input.  tokenizer.rs:33-39
+  // encode(text, add_special_tokens = false), tokenizer.rs:33-39: added tokens are cut out first (longest match), the rest goes
+  // through the Qwen2 pre-tokenisation pattern over Unicode code points (\p{L}, \p{N}, \s from generated tables) and
+  // byte-level BPE.  No normaliser (the Qwen tokenizer.json asks for NFC): the caller passes NFC text.
   std::vector<int64_t> encode(const std::string& text) const;
   size_t vocab_size() const { return id_to_token_.size(); }
 

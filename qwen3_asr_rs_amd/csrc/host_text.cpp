@@ -9,6 +9,7 @@
 #include <sstream>
 
 #include "host.h"
+#include "unicode_tables.h"
 #include "json.h"
 #include "model.h"
 
@@ -43,46 +44,53 @@ std::string read_file(const std::string& path) {
   return ss.str();
 }
 
-bool is_letter(unsigned char c) { return (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'); }
-bool is_digit(unsigned char c) { return c >= '0' && c <= '9'; }
-bool is_space(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+// Unicode classes of the Qwen2 pre-tokenisation pattern (tables generated from unicodedata, unicode_tables.h)
+bool is_letter(uint32_t c) { return c < 0x80 ? ((c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z')) : cp_in(kUnicodeLetter, kUnicodeLetter_n, c); }
+bool is_digit(uint32_t c) { return c < 0x80 ? (c >= '0' && c <= '9') : cp_in(kUnicodeNumber, kUnicodeNumber_n, c); }
+bool is_space(uint32_t c) { return cp_in(kUnicodeSpace, kUnicodeSpace_n, c); }
+// simple case folding of the seven letters the contraction alternative can see (U+017F LONG S folds to s, U+212A KELVIN to k)
+uint32_t fold(uint32_t c) { return (c >= 'A' && c <= 'Z') ? c + 32 : (c == 0x17F ? 's' : c); }
 
-// Qwen2 pre-tokenisation pattern restricted to ASCII:
+// Qwen2 pre-tokenisation pattern over code points (leftmost alternative first, greedy quantifiers, as the regex engine does):
 // (?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+
-size_t match_piece(const std::string& t, size_t i) {
+// t = code points of the text; returns the index one past the piece that starts at i
+size_t match_piece(const std::vector<uint32_t>& t, size_t i) {
   const size_t n = t.size();
-  auto lower = [&](size_t k) { return (char)tolower((unsigned char)t[k]); };
   if (t[i] == '\'' && i + 1 < n) {
-    char a = lower(i + 1);
-    if (a == 's' || a == 't' || a == 'm' || a == 'd') return i + 2;
+    const uint32_t a = fold(t[i + 1]);
+    // alternation order 's 't 're 've 'm 'll 'd: the two-letter forms can only match when the one-letter ones did not
+    if (a == 's' || a == 't') return i + 2;
     if (i + 2 < n) {
-      char b = lower(i + 2);
-      if ((a == 'r' && b == 'e') || (a == 'v' && b == 'e') || (a == 'l' && b == 'l')) return i + 3;
+      const uint32_t b = fold(t[i + 2]);
+      if ((a == 'r' && b == 'e') || (a == 'v' && b == 'e')) return i + 3;
     }
+    if (a == 'm') return i + 2;
+    if (i + 2 < n && a == 'l' && fold(t[i + 2]) == 'l') return i + 3;
+    if (a == 'd') return i + 2;
   }
   {  // [^\r\n L N]? L+
     size_t j = i;
-    unsigned char c = (unsigned char)t[j];
-    if (!(c == '\r' || c == '\n' || is_letter(c) || is_digit(c)) && j + 1 < n && is_letter((unsigned char)t[j + 1])) ++j;
-    if (is_letter((unsigned char)t[j])) {
-      while (j < n && is_letter((unsigned char)t[j])) ++j;
+    const uint32_t c = t[j];
+    if (!(c == '\r' || c == '\n' || is_letter(c) || is_digit(c)) && j + 1 < n && is_letter(t[j + 1])) ++j;
+    if (is_letter(t[j])) {
+      while (j < n && is_letter(t[j])) ++j;
       return j;
     }
   }
-  if (is_digit((unsigned char)t[i])) return i + 1;
+  if (is_digit(t[i])) return i + 1;
   {  // " ?[^\s L N]+[\r\n]*"
     size_t j = i;
-    if (t[j] == ' ' && j + 1 < n) ++j;
-    auto other = [&](size_t k) { unsigned char c = (unsigned char)t[k]; return !is_space(c) && !is_letter(c) && !is_digit(c); };
+    auto other = [&](size_t k) { const uint32_t c = t[k]; return !is_space(c) && !is_letter(c) && !is_digit(c); };
+    if (t[j] == ' ' && j + 1 < n && other(j + 1)) ++j;
     if (j < n && other(j)) {
       while (j < n && other(j)) ++j;
       while (j < n && (t[j] == '\r' || t[j] == '\n')) ++j;
       return j;
     }
   }
-  if (is_space((unsigned char)t[i])) {
+  if (is_space(t[i])) {
     size_t j = i;
-    while (j < n && is_space((unsigned char)t[j])) ++j;  // maximal whitespace run [i, j)
+    while (j < n && is_space(t[j])) ++j;  // maximal whitespace run [i, j)
     size_t last_nl = std::string::npos;
     for (size_t k = i; k < j; ++k)
       if (t[k] == '\r' || t[k] == '\n') last_nl = k;
@@ -171,31 +179,60 @@ std::string BpeTokenizer::decode(const std::vector<int64_t>& ids, bool skip_spec
 }
 
 std::vector<int64_t> BpeTokenizer::encode(const std::string& text) const {
-  for (unsigned char c : text)
-    if (c >= 0x80) fail("Tokenization failed: this encoder handles ASCII prompts only (got a non-ASCII byte)");
+  // tokenizers' AddedVocabulary first cuts the added tokens (special or not) out of the text, longest match at the
+  // leftmost position; the stretches in between go through the pre-tokeniser + byte-level BPE.  (No normaliser: the Qwen
+  // tokenizer.json asks for NFC, so the caller must pass NFC text -- ASCII prompts such as "language English" are.)
   std::vector<int64_t> ids;
-  for (size_t i = 0; i < text.size();) {
-    size_t j = match_piece(text, i);
-    std::vector<std::string> sym;
-    for (size_t k = i; k < j; ++k) sym.push_back(cp_of_byte_[(unsigned char)text[k]]);
-    while (sym.size() > 1) {  // merge the lowest-ranked adjacent pair until none is left
-      int best = INT_MAX;
-      size_t at = 0;
-      for (size_t k = 0; k + 1 < sym.size(); ++k) {
-        auto it = merge_rank_.find(sym[k] + " " + sym[k + 1]);
-        if (it != merge_rank_.end() && it->second < best) { best = it->second; at = k; }
+  auto encode_plain = [&](const std::string& seg) {
+    std::vector<uint32_t> cps;
+    std::vector<size_t> off;  // byte offset of every code point (+ end)
+    for (size_t i = 0; i < seg.size();) { off.push_back(i); cps.push_back(next_cp(seg, i)); }
+    off.push_back(seg.size());
+    for (size_t i = 0; i < cps.size();) {
+      const size_t j = match_piece(cps, i);
+      std::vector<std::string> sym;
+      for (size_t k = off[i]; k < off[j]; ++k) sym.push_back(cp_of_byte_[(unsigned char)seg[k]]);
+      while (sym.size() > 1) {  // merge the lowest-ranked adjacent pair until none is left
+        int best = INT_MAX;
+        size_t at = 0;
+        for (size_t k = 0; k + 1 < sym.size(); ++k) {
+          auto it = merge_rank_.find(sym[k] + " " + sym[k + 1]);
+          if (it != merge_rank_.end() && it->second < best) { best = it->second; at = k; }
+        }
+        if (best == INT_MAX) break;
+        sym[at] += sym[at + 1];
+        sym.erase(sym.begin() + (long)at + 1);
       }
-      if (best == INT_MAX) break;
-      sym[at] += sym[at + 1];
-      sym.erase(sym.begin() + (long)at + 1);
+      for (auto& sy : sym) {
+        auto it = token_to_id_.find(sy);
+        if (it == token_to_id_.end()) fail("Tokenization failed: symbol not in vocabulary");
+        ids.push_back(it->second);
+      }
+      i = j;
     }
-    for (auto& s : sym) {
-      auto it = token_to_id_.find(s);
-      if (it == token_to_id_.end()) fail("Tokenization failed: symbol not in vocabulary");
-      ids.push_back(it->second);
+  };
+  size_t seg0 = 0, i = 0;
+  while (i < text.size()) {
+    size_t best_len = 0;
+    int64_t best_id = -1;
+    if (text[i] == '<' || true) {
+      for (size_t id = 0; id < id_to_token_.size(); ++id) {
+        if (!is_added_[id]) continue;
+        const std::string& tk = id_to_token_[id];
+        if (tk.size() > best_len && !tk.empty() && text.compare(i, tk.size(), tk) == 0) { best_len = tk.size(); best_id = (int64_t)id; }
+      }
     }
-    i = j;
+    if (best_id >= 0) {
+      if (i > seg0) encode_plain(text.substr(seg0, i - seg0));
+      ids.push_back(best_id);
+      i += best_len;
+      seg0 = i;
+    } else {
+      ++i;
+      while (i < text.size() && ((unsigned char)text[i] & 0xC0) == 0x80) ++i;  // next code point boundary
+    }
   }
+  if (seg0 < text.size()) encode_plain(text.substr(seg0));
   return ids;
 }
 

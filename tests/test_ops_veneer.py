@@ -109,7 +109,7 @@ def test_ops_against_torch():
     close(A + B, a + b); close(A - B, a - b); close(A * B, a * b); close(A / B, a / b); close(A.maximum(B), torch.maximum(a, b))
     close(A + 4.0, a + 4.0); close(A - 8.0, a - 8.0); close(A * 0.5, a * 0.5); close(A / 4.0, a / 4.0); close(-A, -a); close(A.neg(), -a)
     close(A.transpose(0, 2) * A.transpose(0, 2), (a * a).transpose(0, 2)); close(A.narrow(2, 0, 1) + B.unsqueeze(0), a[:, :, :1] + b.unsqueeze(0))
-    C = A.contiguous(); C += B; close(C, a + b)
+    C = A + 0.0; C += B; close(C, a + b); close(A, a)   # (+= writes through: a fresh array keeps A intact)
     Z = Tensor.zeros([2, 2]); Z.fill_(3.0); close(Z, torch.full((2, 2), 3.0))
     # math
     p = a.abs() + 0.1

@@ -162,13 +162,18 @@ def test_tokenizer_decode_matches_hf(lib, bpe_json):
         assert mine.decode(ids[:1]) == hf.decode(ids[:1])
 
 
-def test_tokenizer_encode_ascii_matches_hf(lib, bpe_json):
+def test_tokenizer_encode_matches_hf(lib, bpe_json):
+    """tokenizer.rs:33-39 encode(text, false): the forced-language prompt of inference.rs:246-251 and, beyond the reference's
+    own use, arbitrary UTF-8 text -- Unicode letters / numbers / white space in the Qwen2 pre-tokenisation pattern, the
+    case-insensitive contractions, added tokens cut out of the text -- against HuggingFace `tokenizers` on the same file."""
     path, hf = bpe_json
     mine = audio.AsrTokenizer(path)
-    for t in ["language English", "language Chinese", "language Japanese", "it's we'll  two  spaces 42 !? end ", "a\n\nb \n c", "x,y.z"]:
-        assert mine.encode(t) == hf.encode(t, add_special_tokens=False).ids, t
-    with pytest.raises(RuntimeError, match="ASCII"):
-        mine.encode("语言")
+    texts = ["language English", "language Chinese", "language Japanese", "it's 2024! We'll see.\n\nNew line here.  two  spaces ",
+             "IT'S  HE'LL they'RE I'VE i'm we'd 'tis", "tabs\tand\r\nCRLF \n \n", " leading and trailing   ", "a1b22c333 x_y-z (q)!?...",
+             "你好，这是语音识别测试。", "こんにちは 12345 ...  spaces   ", "naïve café Ünïcödé straße ΑΒΓ абв", "全角　空白 and\u00a0nbsp\u2003em",
+             "٣٤٥ ½ ² Ⅷ numbers", "emoji 🙂🙂 mixed🙂text", "language English<asr_text>Hello there.<|im_end|>", "<|im_start|>user\n<asr_text>", "x<asr_text", ""]
+    for t in texts:
+        assert mine.encode(t) == hf.encode(t, add_special_tokens=False).ids, repr(t)
 
 
 def test_parse_and_capitalize_match_oracle(lib):
