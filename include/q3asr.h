@@ -228,7 +228,9 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *   "gemm256_min_tiles"  minimum number of 256x256 output tiles for which the bf16 GEMM dispatches to the 8-wave
  *                        counted-vmcnt kernel (k_gemm256.hip): 0 = whenever the shape allows, a huge value = never.
  *   "dattn_batched_min_wgs"  sequences x kv heads of a decode group from which the batched decode step uses the
- *                        one-workgroup-per-(sequence, kv head) attention kernel (k_dattn.hip) instead of key splits + merge. */
+ *                        one-workgroup-per-(sequence, kv head) attention kernel (k_dattn.hip) instead of key splits + merge.
+ *   "decode_group_size"  sequences per group of the batched decode step (1..32; 0 = 32), taken at the next prefill.
+ *   "decode_parallel_groups"  1: groups run as parallel stream / hipGraph branches (default), 0: one after the other. */
 int32_t q3a_debug_set(const char* key, int32_t value);
 
 /* Kernel self-tests against naive device references (no model needed): returns max abs error. */

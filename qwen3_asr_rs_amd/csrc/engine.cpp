@@ -90,6 +90,9 @@ struct ProfEvent {
 namespace q3a {
 void set_thread_error(const std::string& msg) { g_last_error = msg; }  // used by host_abi.cpp
 }  // namespace q3a
+// A/B knobs of the batched decode step (environment at first use, q3a_debug_set afterwards): sequences per group (0 = 32)
+// and whether the groups run as parallel stream / graph branches (1) or one after the other on the engine's stream (0)
+static int g_decode_group_size = -1, g_decode_parallel_groups = -1;
 
 struct q3a_engine {
   Dims d;
@@ -131,6 +134,12 @@ struct q3a_engine {
   DevBuf zero_page;  // 256 B of zeros: padded filter taps of the bf16 implicit-GEMM convolutions read it
   int part_stride = 0, attn_nsplit = 0;
   size_t kv_layer_elems = 0;
+
+  // ---- batched decode: sequence groups and their streams ----
+  int gsize = 32;  // sequences per group of the batched decode step (<= 32: one skinny-GEMM weight sweep), fixed per batch
+  std::vector<hipStream_t> chain_streams;
+  std::vector<hipEvent_t> join_ev;
+  hipEvent_t fork_ev = nullptr;
 
   // ---- graph ----
   hipGraphExec_t graph_exec = nullptr;
@@ -507,7 +516,10 @@ struct q3a_engine {
     kcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
     vcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
     rope_cur.ensure((size_t)b * 128 * 4);
-    const size_t ng = (size_t)n_groups(b);  // groups of <= 32 sequences of the batched decode step
+    if (g_decode_group_size < 0) { const char* e = getenv("Q3A_DECODE_GROUP"); g_decode_group_size = e ? atoi(e) : 0; }
+    if (g_decode_parallel_groups < 0) { const char* e = getenv("Q3A_DECODE_PARALLEL"); g_decode_parallel_groups = e ? atoi(e) : 1; }
+    gsize = (g_decode_group_size >= 1 && g_decode_group_size <= 32) ? g_decode_group_size : 32;
+    const size_t ng = (size_t)n_groups(b);  // groups of <= gsize sequences of the batched decode step
     nn_x.ensure(ng * 32 * H * 2); nn_ss.ensure(ng * (H / 16) * 32 * 4);
     x_dec.ensure((size_t)b * H * 4); next_tok.ensure((size_t)b * 4); forced_tok.ensure((size_t)b * 4);
     out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
@@ -634,7 +646,7 @@ struct q3a_engine {
   int nn_parts() const { return d.hidden / 16; }  // one partial per 16-column block of a hidden-wide GEMM output
   // Batched decode (more than kGemvMaxSeq sequences) runs in groups of <= 32 sequences: the skinny MFMA GEMM holds 32
   // sequences per weight sweep, and the second group's sweep of a 4-13 MB matrix is served by the L2 / Infinity Cache.
-  static int n_groups(int b) { return b <= kGemvMaxSeq ? 1 : (b + 31) / 32; }
+  int n_groups(int b) const { return b <= kGemvMaxSeq ? 1 : (b + gsize - 1) / gsize; }
   size_t nn_x_stride() const { return (size_t)32 * d.hidden; }         // elements per group
   size_t nn_ss_stride() const { return (size_t)nn_parts() * 32; }
   uint16_t* nn_x_g(int g) const { return nn_x.as<uint16_t>() + (size_t)g * nn_x_stride(); }
@@ -645,7 +657,7 @@ struct q3a_engine {
     NextNormOut nn{};
     if (prenorm_path()) {
       nn.next_w = wf(L.dec[0].in_ln); nn.next_xw16f = nn_x.as<uint16_t>(); nn.next_ss = nn_ss.as<float>(); nn.nparts = nn_parts();
-      nn.group_stride_x = (long)nn_x_stride(); nn.group_stride_ss = (long)nn_ss_stride();
+      nn.group_stride_x = (long)nn_x_stride(); nn.group_stride_ss = (long)nn_ss_stride(); nn.group_size = gsize;
     }
     return nn;
   }
@@ -666,7 +678,7 @@ struct q3a_engine {
 
   // one decoder layer of the greedy-loop iteration (inference.rs:172-197) for sequences [s0, s0 + S) -- the whole batch on
   // the GEMV path, one group of <= 32 on the skinny MFMA path
-  void decode_layer(int li, int grp, int s0, int S) {
+  void decode_layer(int li, int grp, int s0, int S, hipStream_t ks) {
     const int H = d.hidden, I = d.inter, QD = d.q_dim(), QKV = d.qkv_dim();
     const bool qkv_bias = arena_flags & kFlagDecQkvBias, o_bias = arena_flags & kFlagDecOBias, mlp_bias = arena_flags & kFlagDecMlpBias;
     const bool gemv = B <= kGemvMaxSeq;
@@ -686,27 +698,27 @@ struct q3a_engine {
       GemvArgs g{};
       g.x = x; g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
       g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = qkv; g.ldo = QKV;
-      timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, stream)); });
-      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), stream)); });
+      timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, ks)); });
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
       GemvArgs o{};
       if (std::min(S, 4) * d.n_q * attn_nsplit <= GEMV_ATTN_MAX_TABLE) {  // merge the key splits inside the o_proj GEMV
         o.attn_pm = da.pm; o.attn_pl = da.pl; o.attn_po = da.po;
         o.attn_nsplit = attn_nsplit; o.attn_heads = d.n_q; o.attn_fast_exp = precise() ? 0 : 1;
       } else {  // very long contexts: separate merge launch
-        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, attn_nsplit, S, d.n_q, s_ctx_g(grp), stream)); });
+        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, attn_nsplit, S, d.n_q, s_ctx_g(grp), ks)); });
         o.x = s_ctx_g(grp);
       }
       o.ldx = QD; o.W = wh(l.o_w); o.N = H; o.K = QD; o.bias = o_bias ? wf(l.o_b) : nullptr;
       o.mode = 1; o.out = x; o.ldo = H; o.resid = x;
-      timed(Q3A_KC_GEMV_O, 2.0 * H * QD, [&] { KCHK(launch_gemv(o, S, stream)); });
+      timed(Q3A_KC_GEMV_O, 2.0 * H * QD, [&] { KCHK(launch_gemv(o, S, ks)); });
       GemvArgs u{};
       u.x = x; u.ldx = H; u.rms_w = wf(l.post_ln); u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
       u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act_g(grp); u.ldo = I;
-      timed(Q3A_KC_GEMV, 4.0 * I * H, [&] { KCHK(launch_gemv(u, S, stream)); });
+      timed(Q3A_KC_GEMV, 4.0 * I * H, [&] { KCHK(launch_gemv(u, S, ks)); });
       GemvArgs dn{};
       dn.x = s_act_g(grp); dn.ldx = I; dn.W = wh(l.down_w); dn.N = H; dn.K = I; dn.bias = mlp_bias ? wf(l.down_b) : nullptr;
       dn.mode = 1; dn.out = x; dn.ldo = H; dn.resid = x;
-      timed(Q3A_KC_GEMV_DOWN, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, stream)); });
+      timed(Q3A_KC_GEMV_DOWN, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, ks)); });
       return;
     }
     // skinny MFMA GEMMs: the norms are fused (no norm launches), and in the default mode the two K-heavy projections read
@@ -717,50 +729,75 @@ struct q3a_engine {
     if (pre) { q.xw16f = nn_x_g(grp); q.ss_parts = nn_ss_g(grp); q.ss_nparts = nn_parts(); }
     else q.rms_w = wf(l.in_ln);
     q.bias = qkv_bias ? wf(l.qkv_b) : nullptr; q.mode = 0; q.out = qkv; q.ldo = QKV;
-    timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { KCHK(launch_skinny(q, precise(), stream)); });
+    timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { KCHK(launch_skinny(q, precise(), ks)); });
     if (g_dattn_batched_min_wgs < 0) { const char* e = getenv("Q3A_DATTN_BATCHED_MIN_WGS"); g_dattn_batched_min_wgs = e ? atoi(e) : 128; }
     if (S * d.n_kv >= g_dattn_batched_min_wgs) {
       // the group alone fills the chip: one workgroup per (sequence, kv head) walks all keys and writes the context itself
       if (b16) { da.out16 = reinterpret_cast<uint16_t*>(s_ctx_g(grp)); da.out_frag = 1; } else da.out = s_ctx_g(grp);
-      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn_batched(da, S, kv_f32(), stream)); });
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn_batched(da, S, kv_f32(), ks)); });
     } else {
-      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), stream)); });
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, attn_nsplit, S, d.n_q, s_ctx_g(grp), stream, b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr, b16)); });
     }
     SkinnyArgs o{};
     o.x = s_ctx_g(grp); o.x16 = b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr; o.x16_frag = b16; o.ldx = QD; o.S = S; o.W = wh(l.o_w); o.N = H; o.K = QD;
     o.bias = o_bias ? wf(l.o_b) : nullptr; o.mode = 1; o.out = x; o.ldo = H; o.resid = x;
     if (pre) { o.next_w = wf(l.post_ln); o.next_xw16f = nn_x_g(grp); o.next_ss = nn_ss_g(grp); }
-    timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { KCHK(launch_skinny(o, precise(), stream)); });
+    timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { KCHK(launch_skinny(o, precise(), ks)); });
     SkinnyArgs u{};
     u.x = x; u.ldx = H; u.S = S; u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
     if (pre) { u.xw16f = nn_x_g(grp); u.ss_parts = nn_ss_g(grp); u.ss_nparts = nn_parts(); }
     else u.rms_w = wf(l.post_ln);
     u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act_g(grp); u.out16 = b16 ? reinterpret_cast<uint16_t*>(s_act_g(grp)) : nullptr; u.out16_frag = b16; u.ldo = I;
-    timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_skinny(u, precise(), stream)); });
+    timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_skinny(u, precise(), ks)); });
     SkinnyArgs dn{};
     dn.x = s_act_g(grp); dn.x16 = b16 ? reinterpret_cast<uint16_t*>(s_act_g(grp)) : nullptr; dn.x16_frag = b16; dn.ldx = I; dn.S = S; dn.W = wh(l.down_w); dn.N = H; dn.K = I;
     dn.bias = mlp_bias ? wf(l.down_b) : nullptr; dn.mode = 1; dn.out = x; dn.ldo = H; dn.resid = x;
     if (pre && li + 1 < d.dec_layers) {  // (the last layer feeds the final norm + lm_head, which read x_dec)
       dn.next_w = wf(L.dec[li + 1].in_ln); dn.next_xw16f = nn_x_g(grp); dn.next_ss = nn_ss_g(grp);
     }
-    timed(Q3A_KC_GEMM, 2.0 * H * I, [&] { KCHK(launch_skinny(dn, precise(), stream)); });
+    timed(Q3A_KC_GEMM, 2.0 * H * I, [&] { KCHK(launch_skinny(dn, precise(), ks)); });
   }
 
-  // one greedy-loop iteration for all sequences (inference.rs:160-200)
+  // one greedy-loop iteration for all sequences (inference.rs:160-200).  Batched path: the groups of `gsize` sequences are
+  // independent chains of latency-bound kernels (5 per layer), so every group runs on its own stream -- forked from and
+  // joined back into the engine's stream with events, which a hipGraph capture records as parallel branches: one group's
+  // KV-streaming attention overlaps another group's weight-streaming GEMMs.  (Profiling runs keep everything on one stream.)
   void enqueue_decode_step() {
     const int ng = n_groups(B);
-    for (int li = 0; li < d.dec_layers; ++li)
-      for (int g = 0; g < ng; ++g) {
-        const int s0 = ng == 1 ? 0 : g * 32;
-        decode_layer(li, g, s0, ng == 1 ? B : std::min(32, B - s0));
+    const bool chains = ng > 1 && !prof && g_decode_parallel_groups != 0;
+    if (chains) {
+      ensure_chain_streams(ng - 1);
+      HIPCHK(hipEventRecord(fork_ev, stream));
+    }
+    for (int g = 0; g < ng; ++g) {
+      const int s0 = ng == 1 ? 0 : g * gsize;
+      const int S = ng == 1 ? B : std::min(gsize, B - s0);
+      hipStream_t ks = (chains && g > 0) ? chain_streams[g - 1] : stream;
+      if (chains && g > 0) HIPCHK(hipStreamWaitEvent(ks, fork_ev, 0));
+      for (int li = 0; li < d.dec_layers; ++li) decode_layer(li, g, s0, S, ks);
+      if (chains && g > 0) {
+        HIPCHK(hipEventRecord(join_ev[g - 1], ks));
+        HIPCHK(hipStreamWaitEvent(stream, join_ev[g - 1], 0));
       }
+    }
     run_head(1);
+  }
+  void ensure_chain_streams(int n) {
+    while ((int)chain_streams.size() < n) {
+      hipStream_t s2;
+      hipEvent_t e2;
+      HIPCHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+      chain_streams.push_back(s2);
+      join_ev.push_back(e2);
+    }
+    if (!fork_ev) HIPCHK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
   }
 
   std::string make_graph_sig() const {
     char buf[256];
-    snprintf(buf, sizeof(buf), "%d/%d/%d/%p/%p/%p/%p/%p/%p/%p/%p", B, max_ctx, max_new, kcache.p, vcache.p, x_dec.p,
+    snprintf(buf, sizeof(buf), "%d.%d.%d/%d/%d/%p/%p/%p/%p/%p/%p/%p/%p", B, gsize, g_decode_parallel_groups, max_ctx, max_new, kcache.p, vcache.p, x_dec.p,
              logits.p, s_qkv.p, out_ids.p, rope_cos.p, attn_po.p);
     return buf;
   }
@@ -866,6 +903,9 @@ struct q3a_engine {
 
   ~q3a_engine() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    for (auto cs : chain_streams) (void)hipStreamDestroy(cs);
+    for (auto ce : join_ev) (void)hipEventDestroy(ce);
+    if (fork_ev) (void)hipEventDestroy(fork_ev);
     DevBuf* bufs[] = {&dft, &filt_t, &pos_emb, &rope_cos, &rope_sin, &pcm, &d_pcm_off, &d_n_samples, &d_mel_off, &d_n_frames,
                       &mel, &gmax, &d_chunk_utt, &d_chunk_frame0, &conv1, &conv2, &conv3, &conv3_rowmap, &convout_rowmap,
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
@@ -1254,6 +1294,8 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (!key) return 1;
   if (strcmp(key, "gemm256_min_tiles") == 0) { g_gemm256_min_tiles = value; return 0; }
   if (strcmp(key, "dattn_batched_min_wgs") == 0) { g_dattn_batched_min_wgs = value; return 0; }
+  if (strcmp(key, "decode_group_size") == 0) { g_decode_group_size = value; return 0; }
+  if (strcmp(key, "decode_parallel_groups") == 0) { g_decode_parallel_groups = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";
   return 1;
 }

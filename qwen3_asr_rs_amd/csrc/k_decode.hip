@@ -37,9 +37,10 @@ __device__ __forceinline__ void embed_row(const uint16_t* __restrict__ embed, in
   const int tid = threadIdx.x, nthr = blockDim.x;
   const uint2* src = reinterpret_cast<const uint2*>(embed + (size_t)id * H);
   float4* dst = reinterpret_cast<float4*>(x_next + (size_t)s * H);
-  const int sl = s & 31;  // position inside its group of 32 sequences (fragment-order buffers hold one group each)
-  uint16_t* const xw = nn.next_xw16f + (size_t)(s >> 5) * nn.group_stride_x;
-  float* const nss = nn.next_ss + (size_t)(s >> 5) * nn.group_stride_ss;
+  const int gs = nn.group_size > 0 ? nn.group_size : 32;
+  const int sl = s % gs;  // position inside its group of sequences (fragment-order buffers hold one group each)
+  uint16_t* const xw = nn.next_xw16f + (size_t)(s / gs) * nn.group_stride_x;
+  float* const nss = nn.next_ss + (size_t)(s / gs) * nn.group_stride_ss;
   float ss = 0.f;
   for (int i = tid; i < H / 4; i += nthr) {
     const uint2 v = src[i];

@@ -170,6 +170,7 @@ struct NextNormOut {
   int nparts;
   // more than 32 sequences: sequence s belongs to group s / 32, whose buffers start group_stride_* elements further on
   long group_stride_x, group_stride_ss;
+  int group_size;  // sequences per group (0 means 32)
 };
 const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s);
 const char* skinny_init();  // once per device before the first launch_skinny (sets the large-LDS kernel attributes)

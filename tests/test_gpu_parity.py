@@ -155,8 +155,21 @@ def test_batched_decode_attention_and_sequence_groups(tiny_dir):
         _stage_check(tiny_dir, clips, True, steps=3)
         assert lib.q3a_debug_set(b"dattn_batched_min_wgs", 1 << 30) == 0   # key splits + merge on the same groups
         _stage_check(tiny_dir, clips[:35], False, steps=3)
+        # groups of 8 sequences as parallel stream / hipGraph branches: same ids as one group after the other, and oracle parity
+        assert lib.q3a_debug_set(b"dattn_batched_min_wgs", 1) == 0
+        assert lib.q3a_debug_set(b"decode_group_size", 8) == 0
+        _stage_check(tiny_dir, clips[:29], True, steps=3)
+        ids = {}
+        for par in (1, 0):
+            assert lib.q3a_debug_set(b"decode_parallel_groups", par) == 0
+            eng = HipEngine(tiny_dir, 0, max_new_tokens=8)
+            ids[par] = eng.transcribe_batch(clips[:29], None, max_new=8, fixed_new_tokens=8)
+            eng.close()
+        assert ids[0] == ids[1]
     finally:
         lib.q3a_debug_set(b"dattn_batched_min_wgs", 128)
+        lib.q3a_debug_set(b"decode_group_size", 0)
+        lib.q3a_debug_set(b"decode_parallel_groups", 1)
 
 
 def test_mfma_attention_matches_valu_attention(tiny_dir):
