@@ -737,7 +737,7 @@ struct q3a_engine {
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn_batched(da, S, kv_f32(), ks)); });
     } else {
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
-      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, attn_nsplit, S, d.n_q, s_ctx_g(grp), stream, b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr, b16)); });
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, attn_nsplit, S, d.n_q, s_ctx_g(grp), ks, b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr, b16)); });
     }
     SkinnyArgs o{};
     o.x = s_ctx_g(grp); o.x16 = b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr; o.x16_frag = b16; o.ldx = QD; o.S = S; o.W = wh(l.o_w); o.N = H; o.K = QD;
