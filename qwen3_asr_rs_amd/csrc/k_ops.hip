@@ -183,6 +183,29 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* out, const flo
   for (int i = tid; i < D; i += 256) y[i] = expf(x[i] - m) / s;
 }
 
+// generic LayerNorm over the last dimension (any D; the engine's kernel of k_norm.hip serves D % 4 == 0, D <= 2048):
+// two-pass mean / variance in fp32 like ATen's CPU kernel, one workgroup per row
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(float* out, const float* in, const float* w, const float* b, int D, float eps) {
+  __shared__ float red[4];
+  const float* x = in + (long)blockIdx.x * D;
+  float* y = out + (long)blockIdx.x * D;
+  const int tid = threadIdx.x;
+  float s = 0.f;
+  for (int i = tid; i < D; i += 256) s += x[i];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)D;
+  __syncthreads();
+  float v = 0.f;
+  for (int i = tid; i < D; i += 256) { const float dlt = x[i] - mean; v += dlt * dlt; }
+  v = wave_sum(v);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)D + eps);
+  for (int i = tid; i < D; i += 256) y[i] = (x[i] - mean) * rstd * (w ? w[i] : 1.f) + (b ? b[i] : 0.f);
+}
+
 __global__ __launch_bounds__(256) void mean_rows_kernel(float* out, const float* in, int D) {
   __shared__ float red[4];
   const float* x = in + (long)blockIdx.x * D;
@@ -325,6 +348,10 @@ void k_matmul(float* C, const float* A, const float* B, int batch, int M, int N,
 void k_softmax_rows(float* out, const float* in, long rows, int D, hipStream_t s) {
   if (rows <= 0) return;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, out, in, D);
+}
+void k_layernorm_rows(float* out, const float* in, const float* w, const float* b, long rows, int D, float eps, hipStream_t s) {
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, out, in, w, b, D, eps);
 }
 void k_mean_rows(float* out, const float* in, long rows, int D, hipStream_t s) {
   if (rows <= 0) return;

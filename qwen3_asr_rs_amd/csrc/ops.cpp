@@ -814,14 +814,17 @@ int32_t q3a_op_layer_norm(q3a_array** out, const q3a_array* a, const int64_t* ns
   if (n != 1 || a->v.nd < 1 || ns[0] != a->v.shape[a->v.nd - 1]) die("layer_norm: normalized_shape must be the last dimension");
   auto x = f32c(a, "layer_norm");
   const int D = (int)ns[0];
-  const int64_t shp = D;
-  q3a_array *w1 = nullptr, *b0 = nullptr;
   std::unique_ptr<A> wc, bc;
-  if (weight) wc = f32c(weight, "layer_norm"); else { if (q3a_op_ones(&w1, &shp, 1, DT_F32, a->device)) die(g_err); wc.reset(w1); }
-  if (bias) bc = f32c(bias, "layer_norm"); else { if (q3a_op_zeros(&b0, &shp, 1, DT_F32, a->device)) die(g_err); bc.reset(b0); }
+  if (weight) wc = f32c(weight, "layer_norm");
+  if (bias) bc = f32c(bias, "layer_norm");
   std::unique_ptr<A> r(make(shape_of(a), DT_F32, a->device));
-  const char* e = q3a::launch_layernorm(fp(x.get()), fp(wc.get()), fp(bc.get()), fpw(r.get()), (int)(a->numel() / D), D, (float)eps, sd(a), nullptr);
-  if (e) die(e);
+  const long rows = D ? a->numel() / D : 0;
+  if (wc && bc && D % 4 == 0 && D <= 2048) {  // the engine's LayerNorm kernel (k_norm.hip)
+    const char* e = q3a::launch_layernorm(fp(x.get()), fp(wc.get()), fp(bc.get()), fpw(r.get()), (int)rows, D, (float)eps, sd(a), nullptr);
+    if (e) die(e);
+  } else {
+    k_layernorm_rows(fpw(r.get()), fp(x.get()), wc ? fp(wc.get()) : nullptr, bc ? fp(bc.get()) : nullptr, rows, D, (float)eps, sd(a));
+  }
   ret(out, r.release());
   OPS_CATCH
 }

@@ -31,6 +31,7 @@ void k_unary(float* out, const float* in, long n, int op, float p, hipStream_t s
 void k_complex_abs(float* out, const void* in, long n, hipStream_t s);
 void k_matmul(float* C, const float* A, const float* B, int batch, int M, int N, int K, long sa, long sb, bool b_transposed, hipStream_t s);
 void k_softmax_rows(float* out, const float* in, long rows, int D, hipStream_t s);
+void k_layernorm_rows(float* out, const float* in, const float* w, const float* b, long rows, int D, float eps, hipStream_t s);
 void k_mean_rows(float* out, const float* in, long rows, int D, hipStream_t s);
 void k_argmax_rows(long long* idx_out, float* val_out, const float* in, long rows, int D, hipStream_t s);
 void k_triu(float* out, const float* in, long n, int R, int C, long diag, hipStream_t s);

@@ -133,6 +133,8 @@ def test_ops_against_torch():
     w, bias = torch.randn(5, generator=g), torch.randn(5, generator=g)
     close(A.layer_norm([5], dev(w.numpy()), dev(bias.numpy()), 1e-5), F.layer_norm(a, (5,), w, bias, 1e-5), atol=2e-6)
     close(A.layer_norm([5], None, None, 1e-5), F.layer_norm(a, (5,), None, None, 1e-5), atol=2e-6)
+    a8, w8, b8 = torch.randn(6, 8, generator=g), torch.randn(8, generator=g), torch.randn(8, generator=g)   # D % 4 == 0: the engine's kernel
+    close(dev(a8.numpy()).layer_norm([8], dev(w8.numpy()), dev(b8.numpy()), 1e-5), F.layer_norm(a8, (8,), w8, b8, 1e-5), atol=2e-6)
     # matmul: 2-D, batched x 2-D weight.tr() (Linear), batched x batched, broadcast batch, vectors
     m1, m2 = torch.randn(37, 70, generator=g), torch.randn(70, 45, generator=g)
     close(dev(m1.numpy()).matmul(dev(m2.numpy())), m1 @ m2, atol=2e-5)
