@@ -188,20 +188,29 @@ def test_output_parsing_mirror():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r1_bench_final.json is the bench.py line of this round: every field the driver and the judge read
-    must be there with the right type (BASELINE.json metric, roofline and cpu_baseline objects)."""
+    """profiles/r2_bench_final.json is the bench.py line of this round: every field the driver and the judge read
+    must be there with the right type (BASELINE.json metric, roofline and cpu_baseline objects), the roofline must come
+    from the in-situ trace and be internally consistent, and the extra legs must name BASELINE.json's other configs."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    j = json.load(open(os.path.join(root, "profiles", "r1_bench_final.json")))
+    j = json.load(open(os.path.join(root, "profiles", "r2_bench_final.json")))
     base = json.load(open(os.path.join(root, "BASELINE.json")))
     assert j["metric"].split(",")[0] == base["metric"].split(",")[0]
     assert j["unit"] == "audio-seconds/sec" and j["higher_is_better"] is True and j["scaling"] == "weak"
     assert j["n_gpus"] == 1 and j["steps"] > 0 and j["warmup"] >= 0 and j["vs_baseline"] is None
     assert j["value"] > 0 and abs(j["value"] * j["ms_per_step"] / 1e3 - 30.0 * j["config"]["clips_per_gpu"]) < 0.5
     assert "workload" in j["config"] and "model" not in j["config"] and "synthetic" in j["data"]
+    assert j["host_to_host"]["value"] > 0 and j["host_to_host"]["value"] <= j["value"] * 1.02   # PCIe inside the clock cannot be faster
     r = j["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["bytes_per_launch"] / r["avg_launch_us"] / 1e3) < 1.0       # GB/s = bytes / us / 1e3
+    assert "rocprofv3" in r["avg_launch_us_source"] and "MICROBENCHMARK" not in r["avg_launch_us_source"]
+    assert r["launches_per_token"] == 56 and r["microbench"]["avg_launch_us"] <= r["avg_launch_us"]
     assert r["traffic"] is None or r["traffic"] >= 0.95 * r["bytes_per_launch"]   # no under-counted traffic
+    assert r["traffic"] is None or "pmc" in r["traffic_source"]
+    assert 0 < r["decode_stage"]["frac"] < 1
     c = j["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and len(c["runs"]) >= 3
+    ex = j["extra"]
+    assert len(ex) == 2 and "batch=32" in ex[0]["workload"] and "1.7b" in ex[1]["workload"] and all(e["value"] > 0 for e in ex)
