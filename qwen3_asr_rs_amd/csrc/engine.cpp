@@ -131,6 +131,7 @@ struct q3a_engine {
   DevBuf nn_x, nn_ss;  // pre-normalised residual row for the next skinny GEMM: [32 * hidden] bf16 fragment order, [hidden/16][32] f32
   DevBuf rope_cur;  // [B][128] cos|sin row of each sequence's current position (kept by argmax_finalize for decode attention)
   DevBuf enc_ctx16, dec_ctx16;  // opts.valu_attention in the default mode: bf16 copy of the fp32 attention context
+  DevBuf dec_q16;
   DevBuf zero_page;  // 256 B of zeros: padded filter taps of the bf16 implicit-GEMM convolutions read it
   int part_stride = 0, attn_nsplit = 0;
   size_t kv_layer_elems = 0;
@@ -511,6 +512,7 @@ struct q3a_engine {
     const bool valu_attn = kv_f32() || opts.valu_attention;
     dec_x.ensure(Pt * H * 4); dec_ln.ensure(Pt * H * act_elem()); dec_qkv.ensure(Pt * d.qkv_dim() * 4);
     dec_ctx.ensure(Pt * d.q_dim() * (valu_attn ? 4 : act_elem())); dec_act.ensure(Pt * d.inter * act_elem());
+    if (!valu_attn) dec_q16.ensure(Pt * d.q_dim() * 2);  // q after QK-norm + RoPE as bf16 for the MFMA prefill attention
     if (valu_attn && !precise()) dec_ctx16.ensure(Pt * d.q_dim() * 2);
     kv_layer_elems = (size_t)b * d.n_kv * max_ctx * 128;
     kcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
@@ -590,6 +592,7 @@ struct q3a_engine {
     at.scale_div = sqrtf((float)d.head_dim);  // layers.rs:327-328
     const bool valu_attn = kv_f32() || opts.valu_attention;
     at.o16 = valu_attn ? nullptr : dec_ctx.as<uint16_t>();
+    if (!valu_attn) { at.q16 = dec_q16.as<uint16_t>(); at.q_rs = QD; }  // the rope kernel leaves q as bf16 [rows][QD]
     const DevBuf& ctx_in = (valu_attn && !sp) ? dec_ctx16 : dec_ctx;  // what the o projection reads
     const bool qkv_bias = arena_flags & kFlagDecQkvBias, o_bias = arena_flags & kFlagDecOBias, mlp_bias = arena_flags & kFlagDecMlpBias;
     for (int li = 0; li < d.dec_layers; ++li) {
@@ -604,6 +607,7 @@ struct q3a_engine {
       rk.q_norm = wf(l.q_norm); rk.k_norm = wf(l.k_norm); rk.eps = d.rms_eps;
       rk.cos_t = rope_cos.as<float>(); rk.sin_t = rope_sin.as<float>();
       rk.kcache = kc_layer(li); rk.vcache = vc_layer(li); rk.n_q = d.n_q; rk.n_kv = d.n_kv; rk.max_ctx = max_ctx;
+      rk.q16 = valu_attn ? nullptr : dec_q16.as<uint16_t>();
       KCHK(launch_qknorm_rope_kv(rk, total_P, kv_f32(), stream));
       at.k = kc_layer(li); at.v = vc_layer(li);
       if (valu_attn) {
@@ -911,7 +915,7 @@ struct q3a_engine {
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
                       &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
                       &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po,
-                      &enc_ctx16, &dec_ctx16, &zero_page, &rope_cur, &nn_x, &nn_ss};
+                      &enc_ctx16, &dec_ctx16, &dec_q16, &zero_page, &rope_cur, &nn_x, &nn_ss};
     for (auto* b : bufs) b->release();
     for (auto& kv : taps) kv.second.release();
     if (own_arena && arena) (void)hipFree(arena);

@@ -89,8 +89,14 @@ __global__ __launch_bounds__(256) void qknorm_rope_kv_kernel(RopeKvArgs a, int r
   const int pos = a.row_pos[row], seq = a.row_seq[row];
   if (hv < a.n_q) {
     head_norm_rope(x1, x2, a.q_norm, a.eps, a.cos_t, a.sin_t, pos, lane);
-    base[lane] = x1;
-    base[lane + 64] = x2;
+    if (a.q16) {
+      uint16_t* q = a.q16 + (size_t)row * a.n_q * 128 + (size_t)hv * 128;
+      q[lane] = (uint16_t)f32_to_bf16_bits(x1);
+      q[lane + 64] = (uint16_t)f32_to_bf16_bits(x2);
+    } else {
+      base[lane] = x1;
+      base[lane + 64] = x2;
+    }
   } else {
     const bool is_k = hv < a.n_q + a.n_kv;
     const int kvh = is_k ? hv - a.n_q : hv - a.n_q - a.n_kv;

@@ -247,6 +247,7 @@ const char* launch_fattn_enc(const AttnArgs& a, hipStream_t s) {
 const char* launch_fattn_prefill(const AttnArgs& a, int group, hipStream_t s) {
   if (a.n_segs <= 0) return nullptr;
   if (a.q_rs % 4 != 0 || a.o_rs % 4 != 0) return "fattn: row strides must be multiples of 4";
+  if (a.q16 && a.q_rs % 8 != 0) return "fattn: bf16 q row stride must be a multiple of 8";
   if (group == 1) launch_f<128, 1, true, uint16_t>(a, s);
   else if (group == 2) launch_f<128, 2, true, uint16_t>(a, s);
   else if (group == 4) launch_f<128, 4, true, uint16_t>(a, s);

@@ -386,8 +386,15 @@ const char* launch_gemm16(const uint16_t* X, int lda, const uint16_t* W, int M, 
                           bool glu, hipStream_t s) {
   if (M <= 0) return nullptr;
   if (K % 32 != 0 || lda % 8 != 0) return "gemm16: K must be a multiple of 32 and lda of 8";
-  if (glu && N % 32 != 0) return "gemm16: GLU needs N % 32 == 0";
   if (K % 64 == 0 && gemm256_eligible(M, N, K)) return launch_gemm256(X, lda, W, M, N, K, ep, glu, s);
+  return launch_gemm16_small(X, lda, W, M, N, K, ep, glu, s);
+}
+
+const char* launch_gemm16_small(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
+                                bool glu, hipStream_t s) {
+  if (M <= 0) return nullptr;
+  if (K % 32 != 0 || lda % 8 != 0) return "gemm16: K must be a multiple of 32 and lda of 8";
+  if (glu && N % 32 != 0) return "gemm16: GLU needs N % 32 == 0";
   DenseA16 A{X, lda};
   // few tiles and a long K: 32x32 tiles whose 4 waves split K (A/B knob: Q3A_GEMM16_KSPLIT=0 disables)
   static const bool ksplit_on = [] { const char* e = getenv("Q3A_GEMM16_KSPLIT"); return !e || atoi(e) != 0; }();

@@ -400,6 +400,30 @@ const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M,
   if (K % G_BK != 0 || K < 2 * G_BK || lda % 8 != 0) return "gemm256: K must be a multiple of 64 (>= 128) and lda of 8";
   if (glu && N % 32 != 0) return "gemm256: GLU needs N % 32 == 0";
   if (N % 4 != 0 || ep.ldo % 4 != 0) return "gemm256: N and ldo must be multiples of 4 (vector epilogue)";
+  // Wave quantisation: one workgroup per CU, so T tiles take ceil(T / 256) rounds.  When the last round would be mostly
+  // empty (encoder qkv at 32 clips: 539 tiles = 2 rounds + 27 tiles), the leading tile rows that fill whole rounds run here
+  // and the remaining rows go to the small-tile kernel of k_gemm16.hip (its own launch, many cheap tiles).
+  static const int rem_max = [] { const char* e = getenv("Q3A_GEMM256_SPLIT_REM"); return e ? atoi(e) : 96; }();  // A/B knob (0 = off)
+  const int tiles_m = (M + G_BM - 1) / G_BM, tiles_n = (N + G_BN - 1) / G_BN;
+  const long tiles = (long)tiles_m * tiles_n;
+  const int rem = (int)(tiles % 256);
+  if (rem_max > 0 && tiles > 256 && rem > 0 && rem <= rem_max && !ep.addend) {
+    const int rows_m = (int)((tiles - rem) / tiles_n);  // whole tile rows inside the full rounds
+    const int M1 = rows_m * G_BM;
+    if (rows_m >= 1 && M1 < M) {
+      DenseA256 A1{X, lda};
+      if (glu) launch256<true>(A1, W, nullptr, M1, N, K, ep, s); else launch256<false>(A1, W, nullptr, M1, N, K, ep, s);
+      GemmEpilogue e2 = ep;
+      if (ep.rowmap) e2.rowmap = ep.rowmap + M1;  // the map is indexed by GEMM row; outputs stay absolute
+      else {
+        const size_t off = (size_t)M1 * ep.ldo;
+        if (e2.out) e2.out += off;
+        if (e2.out16) e2.out16 += off;
+        if (e2.resid) e2.resid += off;
+      }
+      return launch_gemm16_small(X + (size_t)M1 * lda, lda, W, M - M1, N, K, e2, glu, s);
+    }
+  }
   DenseA256 A{X, lda};
   if (glu) launch256<true>(A, W, nullptr, M, N, K, ep, s); else launch256<false>(A, W, nullptr, M, N, K, ep, s);
   return nullptr;

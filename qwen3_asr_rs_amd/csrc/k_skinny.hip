@@ -110,7 +110,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     uint4 wv[WLDS ? 1 : UNR][TILES];
     float4 x0[UNR][SH], x1[UNR][SH], w0[UNR], w1[UNR];
     uint4 xq[UNR][SH];
-    if (WLDS) {  // the launcher guarantees ks1 - ks0 == UNR here: one pass
+    if (WLDS) {  // the launcher guarantees (ks1 - ks0) % UNR == 0: whole passes.  A later pass refills the wave's private region
+                 // after this wave's own fragment reads of the previous pass were consumed by its MFMAs (program order)
       const int rr = lane >> 3, p = lane & 7;
 #pragma unroll
       for (int t = 0; t < TILES; ++t)
@@ -281,7 +282,9 @@ void launch_k(const SkinnyArgs& a, dim3 grid, hipStream_t s) {
   const size_t wbytes = (size_t)SK_WAVES * TILES * (UNR / 2) * 2048;
   static const bool wlds_on = [] { const char* e = getenv("Q3A_SKINNY_WLDS"); return !e || atoi(e) != 0; }();  // A/B knob
   if constexpr (UNR % 2 == 0 && !SPLIT) {
-    if (wlds_on && per == UNR && steps % per == 0 && wbytes <= sk_dyn_lds_max(TILES, SH)) {
+    // (K = 6144 at 1.7B: 24 steps per wave = two passes of 12; before, such shapes fell back to direct fragment loads:
+    // down projection 14.8 us for 25 MB)
+    if (wlds_on && per % UNR == 0 && steps % per == 0 && wbytes <= sk_dyn_lds_max(TILES, SH)) {
       // dynamic LDS above the 64 KiB default: the attribute is set by skinny_init() (not here: this may run under capture)
       hipLaunchKernelGGL((skinny_kernel<SPLIT, TILES, SH, XMODE, UNR, true>), grid, block, wbytes, s, a);
       return;

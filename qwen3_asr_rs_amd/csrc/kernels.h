@@ -34,6 +34,9 @@ const char* launch_conv3x3s2_gemm16(const uint16_t* X, const uint16_t* zero_page
 // 256 x 256 x 64, 8-wave, counted-vmcnt version of the two above for batch-sized problems (k_gemm256.hip); launch_gemm16 /
 // launch_conv3x3s2_gemm16 dispatch to it when gemm256_eligible (enough 256 x 256 tiles, K % 64 == 0, K >= 128)
 bool gemm256_eligible(int M, int N, int K);
+// launch_gemm16 without the dispatch to gemm256 (the 4-wave tiles of k_gemm16.hip): small problems and gemm256's split remainder
+const char* launch_gemm16_small(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
+                                bool glu, hipStream_t s);
 extern int g_gemm256_min_tiles;  // A/B knob, see k_gemm256.hip
 extern int g_dattn_batched_min_wgs;  // A/B knob, see k_dattn.hip: S * n_kv at which the decode step uses launch_decode_attn_batched
 const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
@@ -112,6 +115,8 @@ struct RopeKvArgs {
   const float* cos_t; const float* sin_t;  // [max_pos][64]
   void* kcache; void* vcache;              // this layer: [S][n_kv][max_ctx][128]
   int n_q, n_kv, max_ctx;
+  uint16_t* q16;            // non-null (default mode, MFMA attention): q is written HERE as bf16 [rows][n_q*128] -- the value the
+                            // attention kernel rounds it to on load anyway -- instead of in place as fp32 (half the bytes twice)
 };
 const char* launch_qknorm_rope_kv(const RopeKvArgs& a, int rows, bool kv_f32, hipStream_t s);
 // dst[i] = src[row_idx[i]]
