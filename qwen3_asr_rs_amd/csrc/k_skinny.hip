@@ -60,7 +60,7 @@ __device__ __forceinline__ float sq4(const float4& a) { return a.x * a.x + a.y *
 // WLDS: the wave's weight slab goes HBM -> LDS by DMA (global_load_lds, non-temporal) in 8-row x 128-B pieces -- 8
 // cache lines per wave instruction instead of the 16 of a direct fragment load, which the L1 retires twice as fast
 // -- into a wave-private region (no barrier: the wave waits for its own DMA), swizzled like k_gemm16.hip so that the
-// fragment reads (ds_read_b128, 16 rows x 16 B) are conflict-free.  Needs UNR == K/32/8 (the whole slice at once).
+// fragment reads (ds_read_b128, 16 rows x 16 B) are conflict-free.  The wave slice is consumed in passes of UNR steps (one pass when UNR == K/32/8).
 template <bool SPLIT, int TILES, int SH, int XMODE, int UNR, bool WLDS>
 __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   static_assert(!(SPLIT && XMODE >= 2), "the precise mode keeps fp32 activations");
