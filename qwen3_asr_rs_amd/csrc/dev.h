@@ -97,6 +97,21 @@ __device__ __forceinline__ float gelu_fast(float x) {
   const float pe = poly * __expf(-z * z);  // erfc(|x| / sqrt 2)
   return 0.5f * x * (x >= 0.f ? 2.0f - pe : pe);
 }
+// the same on a channel pair: every multiply / fma is one packed instruction for both values
+__device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t x) {
+  const f32x2_t z = f32x2_t{fabsf(x.x), fabsf(x.y)} * f32x2_t{0.70710678118654752440f, 0.70710678118654752440f};
+  const f32x2_t d = f32x2_t{1.0f, 1.0f} + f32x2_t{0.3275911f, 0.3275911f} * z;
+  const f32x2_t t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  f32x2_t poly = f32x2_t{1.061405429f, 1.061405429f} * t - f32x2_t{1.453152027f, 1.453152027f};
+  poly = poly * t + f32x2_t{1.421413741f, 1.421413741f};
+  poly = poly * t - f32x2_t{0.284496736f, 0.284496736f};
+  poly = poly * t + f32x2_t{0.254829592f, 0.254829592f};
+  poly = poly * t;
+  const f32x2_t nz2 = -(z * z);
+  const f32x2_t pe = poly * f32x2_t{__expf(nz2.x), __expf(nz2.y)};
+  const f32x2_t hx = f32x2_t{0.5f, 0.5f} * x;
+  return f32x2_t{hx.x * (x.x >= 0.f ? 2.0f - pe.x : pe.x), hx.y * (x.y >= 0.f ? 2.0f - pe.y : pe.y)};
+}
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // SiLU (reference: Tensor::silu, src/tensor.rs:354-356)
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }

@@ -93,6 +93,8 @@ void set_thread_error(const std::string& msg) { g_last_error = msg; }  // used b
 // A/B knobs of the batched decode step (environment at first use, q3a_debug_set afterwards): sequences per group (0 = 32)
 // and whether the groups run as parallel stream / graph branches (1) or one after the other on the engine's stream (0)
 static int g_decode_group_size = -1, g_decode_parallel_groups = -1;
+// A/B knob: QK-norm + RoPE + cache append as the qkv GEMM's epilogue in batch-sized prefills (Q3A_FUSE_QKROPE, default on)
+static int g_fuse_qkrope = -1;
 
 struct q3a_engine {
   Dims d;
@@ -595,20 +597,25 @@ struct q3a_engine {
     if (!valu_attn) { at.q16 = dec_q16.as<uint16_t>(); at.q_rs = QD; }  // the rope kernel leaves q as bf16 [rows][QD]
     const DevBuf& ctx_in = (valu_attn && !sp) ? dec_ctx16 : dec_ctx;  // what the o projection reads
     const bool qkv_bias = arena_flags & kFlagDecQkvBias, o_bias = arena_flags & kFlagDecOBias, mlp_bias = arena_flags & kFlagDecMlpBias;
+    if (g_fuse_qkrope < 0) { const char* e = getenv("Q3A_FUSE_QKROPE"); g_fuse_qkrope = e ? atoi(e) : 1; }
+    const bool fuse_rope = g_fuse_qkrope != 0 && !valu_attn && !precise() && d.head_dim == 128 && gemm256_eligible(total_P, QKV, H) && H % 64 == 0;
     for (int li = 0; li < d.dec_layers; ++li) {
       const DecLayerOff& l = L.dec[li];
       KCHK(launch_rmsnorm(dec_x.as<float>(), wf(l.in_ln), dec_ln.as<float>(), total_P, H, d.rms_eps, stream, act16(dec_ln)));
-      {
-        GemmEpilogue ep; ep.out = dec_qkv.as<float>(); ep.ldo = QKV; ep.bias = qkv_bias ? wf(l.qkv_b) : nullptr;
-        act_gemm(dec_ln, H, wh(l.qkv_w), total_P, QKV, H, ep, false);
-      }
       RopeKvArgs rk{};
       rk.qkv = dec_qkv.as<float>(); rk.row_seq = row_seq.as<int>(); rk.row_pos = row_pos.as<int>();
       rk.q_norm = wf(l.q_norm); rk.k_norm = wf(l.k_norm); rk.eps = d.rms_eps;
       rk.cos_t = rope_cos.as<float>(); rk.sin_t = rope_sin.as<float>();
       rk.kcache = kc_layer(li); rk.vcache = vc_layer(li); rk.n_q = d.n_q; rk.n_kv = d.n_kv; rk.max_ctx = max_ctx;
       rk.q16 = valu_attn ? nullptr : dec_q16.as<uint16_t>();
-      KCHK(launch_qknorm_rope_kv(rk, total_P, kv_f32(), stream));
+      if (fuse_rope) {
+        // batch-sized prefill: QK-norm, RoPE and the cache append are the epilogue of the qkv GEMM (k_gemm256.hip)
+        KCHK(launch_gemm256_qkrope(dec_ln.as<uint16_t>(), H, wh(l.qkv_w), total_P, H, qkv_bias ? wf(l.qkv_b) : nullptr, rk, stream));
+      } else {
+        GemmEpilogue ep; ep.out = dec_qkv.as<float>(); ep.ldo = QKV; ep.bias = qkv_bias ? wf(l.qkv_b) : nullptr;
+        act_gemm(dec_ln, H, wh(l.qkv_w), total_P, QKV, H, ep, false);
+        KCHK(launch_qknorm_rope_kv(rk, total_P, kv_f32(), stream));
+      }
       at.k = kc_layer(li); at.v = vc_layer(li);
       if (valu_attn) {
         KCHK(launch_attn_prefill(at, d.n_q / d.n_kv, kv_f32(), stream));
@@ -1300,6 +1307,7 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (strcmp(key, "dattn_batched_min_wgs") == 0) { g_dattn_batched_min_wgs = value; return 0; }
   if (strcmp(key, "decode_group_size") == 0) { g_decode_group_size = value; return 0; }
   if (strcmp(key, "decode_parallel_groups") == 0) { g_decode_parallel_groups = value; return 0; }
+  if (strcmp(key, "fuse_qkrope") == 0) { g_fuse_qkrope = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";
   return 1;
 }

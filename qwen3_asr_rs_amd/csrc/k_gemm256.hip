@@ -108,9 +108,12 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else Q3A_WAIT_VM(8);
 }
 
-template <bool GLU, class ALoader>
+// ROPE: the qkv projection of the prefill with the per-head RMSNorm, RoPE and KV-cache append of
+// qknorm_rope_kv_kernel (k_decode.hip) as its epilogue -- see the epilogue below.
+template <bool GLU, class ALoader, bool ROPE = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16_t* __restrict__ Wt,
-                                                         const uint16_t* __restrict__ zero, int M, int N, int K, GemmEpilogue ep) {
+                                                         const uint16_t* __restrict__ zero, int M, int N, int K, GemmEpilogue ep,
+                                                         RopeKvArgs rk) {
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * G_BUF];  // the ONLY LDS object of this kernel
 
   const int tiles_m = (M + G_BM - 1) / G_BM, tiles_n = (N + G_BN - 1) / G_BN;
@@ -310,7 +313,67 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[(i * 16 + row_in + r) * 64 + j * 16 + col_in] = acc[h * 4 + i][j][r];
     const int mrow0 = m0 + wr * 128 + h * 64;
-    if (!GLU) {
+    if constexpr (ROPE) {
+      // A 128-wide head = the 64-column tiles of the wave pair (wc, wc ^ 1): column c of the even wave and column c of the
+      // odd wave are the rotate_half partners (dims c, c + 64).  Both halves are staged; after a workgroup barrier a lane
+      // reads its own 4 columns and the partner's 4 at the same offset, the 16 lanes of a row reduce the 128 squares with
+      // DPP, and q leaves as bf16 [rows][n_q * 128], k / v go to their cache rows (src/layers.rs:303-319,361-375) --
+      // the fp32 qkv matrix (16 KiB per token at 0.6B) is never written or re-read.
+      __syncthreads();
+      const float* pst = reinterpret_cast<const float*>(lds + (wave ^ 1) * 16384);
+      const int c4 = (lane & 15) * 4;
+      const int ncol = n0 + wc * 64;               // first W row of this wave's columns
+      const int hv = ncol >> 7;                    // head vector index: q heads, then k heads, then v heads
+      const bool second = (wc & 1) != 0;           // this wave holds dims 64..127 of the head
+      const int d_own = (second ? 64 : 0) + c4, d_par = (second ? 0 : 64) + c4;
+      const bool is_q = hv < rk.n_q, is_k = !is_q && hv < rk.n_q + rk.n_kv;
+      const float* nw = is_q ? rk.q_norm : rk.k_norm;
+      float4 w_own = make_float4(1.f, 1.f, 1.f, 1.f), w_par = w_own;
+      if (is_q || is_k) {
+        w_own = *reinterpret_cast<const float4*>(nw + d_own);
+        w_par = *reinterpret_cast<const float4*>(nw + d_par);
+      }
+      float4 b_own = make_float4(0.f, 0.f, 0.f, 0.f), b_par = b_own;
+      if (ep.bias && ncol < N) {
+        b_own = *reinterpret_cast<const float4*>(ep.bias + (hv << 7) + d_own);
+        b_par = *reinterpret_cast<const float4*>(ep.bias + (hv << 7) + d_par);
+      }
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4), m = mrow0 + row;
+        const int mc = m < M ? m : M - 1;
+        float4 xo = *reinterpret_cast<const float4*>(&stg[row * 64 + c4]);
+        float4 xp = *reinterpret_cast<const float4*>(&pst[row * 64 + c4]);
+        const int pos = rk.row_pos[mc];
+        xo.x += b_own.x; xo.y += b_own.y; xo.z += b_own.z; xo.w += b_own.w;
+        xp.x += b_par.x; xp.y += b_par.y; xp.z += b_par.z; xp.w += b_par.w;
+        float4 v = xo;
+        if (is_q || is_k) {  // wave-uniform
+          const float4 cs = *reinterpret_cast<const float4*>(rk.cos_t + (size_t)pos * 64 + c4);
+          const float4 sn = *reinterpret_cast<const float4*>(rk.sin_t + (size_t)pos * 64 + c4);
+          float ss = xo.x * xo.x + xo.y * xo.y + xo.z * xo.z + xo.w * xo.w + xp.x * xp.x + xp.y * xp.y + xp.z * xp.z + xp.w * xp.w;
+          ss = row16_sum(ss);
+          const float rstd = 1.0f / sqrtf(ss / 128.0f + rk.eps);
+          const float4 no = make_float4((xo.x * rstd) * w_own.x, (xo.y * rstd) * w_own.y, (xo.z * rstd) * w_own.z, (xo.w * rstd) * w_own.w);
+          float4 np = make_float4((xp.x * rstd) * w_par.x, (xp.y * rstd) * w_par.y, (xp.z * rstd) * w_par.z, (xp.w * rstd) * w_par.w);
+          if (!second) { np.x = -np.x; np.y = -np.y; np.z = -np.z; np.w = -np.w; }  // rotate_half = cat(-x2, x1)
+          v = make_float4(no.x * cs.x + np.x * sn.x, no.y * cs.y + np.y * sn.y, no.z * cs.z + np.z * sn.z, no.w * cs.w + np.w * sn.w);
+        }
+        if (m >= M || ncol >= N) continue;
+        uint2 pk;
+        pk.x = pack_bf16x2(v.x, v.y);
+        pk.y = pack_bf16x2(v.z, v.w);
+        if (is_q) {
+          *reinterpret_cast<uint2*>(rk.q16 + (size_t)m * rk.n_q * 128 + (size_t)hv * 128 + d_own) = pk;
+        } else {
+          const int kvh = is_k ? hv - rk.n_q : hv - rk.n_q - rk.n_kv;
+          uint16_t* c = reinterpret_cast<uint16_t*>(is_k ? rk.kcache : rk.vcache) +
+                        (((size_t)rk.row_seq[mc] * rk.n_kv + kvh) * rk.max_ctx + pos) * 128 + d_own;
+          *reinterpret_cast<uint2*>(c) = pk;
+        }
+      }
+      __syncthreads();  // the partner is done with this wave's staged half before the next pass overwrites it
+    } else if (!GLU) {
       const int c4 = (lane & 15) * 4, n = n0 + wc * 64 + c4;
 #pragma unroll 4
       for (int it = 0; it < 16; ++it) {
@@ -373,10 +436,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
   }
 }
 
-template <bool GLU, class ALoader>
-void launch256(const ALoader& A, const uint16_t* W, const uint16_t* zero, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s) {
+template <bool GLU, class ALoader, bool ROPE = false>
+void launch256(const ALoader& A, const uint16_t* W, const uint16_t* zero, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s,
+               const RopeKvArgs& rk = RopeKvArgs{}) {
   const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-  hipLaunchKernelGGL((gemm256_kernel<GLU, ALoader>), dim3(tiles), dim3(512), 0, s, A, W, zero, M, N, K, ep);
+  hipLaunchKernelGGL((gemm256_kernel<GLU, ALoader, ROPE>), dim3(tiles), dim3(512), 0, s, A, W, zero, M, N, K, ep, rk);
 }
 
 }  // namespace
@@ -390,6 +454,9 @@ bool gemm256_eligible(int M, int N, int K) {
     g_gemm256_min_tiles = e ? atoi(e) : 128;
   }
   if (K % 32 != 0 || K < 2 * G_BK || N % 4 != 0) return false;
+  // a few rows against a wide matrix (the decode-step lm_head at 5..64 sequences) is a weight stream, not MFMA work:
+  // the 32-row tiles of the small kernel read it at 5.3 TB/s, a 256-row tile at 4.4 (58.8 vs 70 us for 32 x 151936)
+  if (M < 128) return false;
   const long tiles = (long)((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
   return tiles >= g_gemm256_min_tiles;
 }
@@ -426,6 +493,19 @@ const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M,
   }
   DenseA256 A{X, lda};
   if (glu) launch256<true>(A, W, nullptr, M, N, K, ep, s); else launch256<false>(A, W, nullptr, M, N, K, ep, s);
+  return nullptr;
+}
+
+const char* launch_gemm256_qkrope(const uint16_t* X, int lda, const uint16_t* W, int M, int K, const float* bias,
+                                  const RopeKvArgs& rk, hipStream_t s) {
+  if (M <= 0) return nullptr;
+  const int N = (rk.n_q + 2 * rk.n_kv) * 128;
+  if (K % G_BK != 0 || K < 2 * G_BK || lda % 8 != 0) return "gemm256 qkrope: K must be a multiple of 64 (>= 128) and lda of 8";
+  if (!rk.q16 || !rk.kcache || !rk.vcache || !rk.row_pos || !rk.row_seq) return "gemm256 qkrope: bf16 q / KV cache / row tables required";
+  GemmEpilogue ep;
+  ep.bias = bias;
+  DenseA256 A{X, lda};
+  launch256<false, DenseA256, true>(A, W, nullptr, M, N, K, ep, s, rk);
   return nullptr;
 }
 

@@ -119,6 +119,10 @@ struct RopeKvArgs {
                             // attention kernel rounds it to on load anyway -- instead of in place as fp32 (half the bytes twice)
 };
 const char* launch_qknorm_rope_kv(const RopeKvArgs& a, int rows, bool kv_f32, hipStream_t s);
+// qkv projection (bf16 X [M][K] . W[(n_q + 2 n_kv) * 128][K]^T + bias) with the kernel above as its epilogue: q -> a.q16, k / v
+// -> bf16 KV cache; a.qkv is not touched.  256 x 256 tiles (k_gemm256.hip): call when gemm256_eligible(M, N, K).
+const char* launch_gemm256_qkrope(const uint16_t* X, int lda, const uint16_t* W, int M, int K, const float* bias,
+                                  const RopeKvArgs& a, hipStream_t s);
 // dst[i] = src[row_idx[i]]
 const char* launch_gather_rows(const float* src, const int* row_idx, int n, int D, float* dst, hipStream_t s);
 // dst[dst_row[i]] = src[i]  (negative dst_row: skip)

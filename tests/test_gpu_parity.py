@@ -172,6 +172,39 @@ def test_batched_decode_attention_and_sequence_groups(tiny_dir):
         lib.q3a_debug_set(b"decode_parallel_groups", 1)
 
 
+def test_fused_qknorm_rope_epilogue_of_the_qkv_gemm(tiny_dir, tiny_untied_dir):
+    """Batch-sized prefills run QK-norm + RoPE + the KV-cache append as the epilogue of the 256x256 qkv GEMM.  Forced on
+    at tiny dims (ragged row count: the last row tile is partial; GQA ratios 2 and 4, qkv bias in the untied preset),
+    checked against the oracle (prefill logits, then teacher-forced decode steps that read the cache the epilogue
+    wrote) and against the separate-kernel path on the same inputs."""
+    from qwen3_asr_rs_amd import _lib
+    lib = _lib.load()
+    clips = [synthetic.synthetic_clip(60 + i, 2.0 + 0.53 * i) for i in range(7)]
+    try:
+        assert lib.q3a_debug_set(b"gemm256_min_tiles", 0) == 0
+        for d in (tiny_dir, tiny_untied_dir):
+            got = {}
+            for fuse in (1, 0):
+                assert lib.q3a_debug_set(b"fuse_qkrope", fuse) == 0
+                if fuse:
+                    _stage_check(d, clips, False, steps=3)
+                eng = HipEngine(d, 0, debug_taps=True, max_new_tokens=8)
+                eng.mel(clips)
+                eng.encode()
+                prompts = [HipEngine.build_prompt(eng.num_audio_tokens(len(c))) for c in clips]
+                assert sum(len(p) for p in prompts) >= 128   # the 256-row-tile kernel takes the qkv projection
+                logits, _ = eng.prefill(prompts)
+                eng.set_next_tokens([11] * len(clips))
+                lg, _, _ = eng.decode_step()
+                got[fuse] = (logits.copy(), lg.copy())
+                eng.close()
+            for a, b in zip(got[1], got[0]):
+                assert rel_l2(a, b) <= 2e-3
+    finally:
+        lib.q3a_debug_set(b"gemm256_min_tiles", 128)
+        lib.q3a_debug_set(b"fuse_qkrope", 1)
+
+
 def test_mfma_attention_matches_valu_attention(tiny_dir):
     """Default mode: the MFMA flash-attention kernels against the fp32 VALU kernels on the same inputs
     (two windows in the encoder, ragged causal prefill)."""
