@@ -461,6 +461,18 @@ bool gemm256_eligible(int M, int N, int K) {
   return tiles >= g_gemm256_min_tiles;
 }
 
+// Rows [0, M1) that fill whole rounds of 256 tiles when the last round would hold at most `rem_max` tiles (0: no split).
+static int split_rows(int M, int N) {
+  static const int rem_max = [] { const char* e = getenv("Q3A_GEMM256_SPLIT_REM"); return e ? atoi(e) : 96; }();  // A/B knob (0 = off)
+  const int tiles_m = (M + G_BM - 1) / G_BM, tiles_n = (N + G_BN - 1) / G_BN;
+  const long tiles = (long)tiles_m * tiles_n;
+  const int rem = (int)(tiles % 256);
+  if (rem_max <= 0 || tiles <= 256 || rem == 0 || rem > rem_max) return 0;
+  const int rows_m = (int)((tiles - rem) / tiles_n);  // whole tile rows inside the full rounds
+  const int M1 = rows_m * G_BM;
+  return (rows_m >= 1 && M1 < M) ? M1 : 0;
+}
+
 const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
                            bool glu, hipStream_t s) {
   if (M <= 0) return nullptr;
@@ -470,14 +482,9 @@ const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M,
   // Wave quantisation: one workgroup per CU, so T tiles take ceil(T / 256) rounds.  When the last round would be mostly
   // empty (encoder qkv at 32 clips: 539 tiles = 2 rounds + 27 tiles), the leading tile rows that fill whole rounds run here
   // and the remaining rows go to the small-tile kernel of k_gemm16.hip (its own launch, many cheap tiles).
-  static const int rem_max = [] { const char* e = getenv("Q3A_GEMM256_SPLIT_REM"); return e ? atoi(e) : 96; }();  // A/B knob (0 = off)
-  const int tiles_m = (M + G_BM - 1) / G_BM, tiles_n = (N + G_BN - 1) / G_BN;
-  const long tiles = (long)tiles_m * tiles_n;
-  const int rem = (int)(tiles % 256);
-  if (rem_max > 0 && tiles > 256 && rem > 0 && rem <= rem_max && !ep.addend) {
-    const int rows_m = (int)((tiles - rem) / tiles_n);  // whole tile rows inside the full rounds
-    const int M1 = rows_m * G_BM;
-    if (rows_m >= 1 && M1 < M) {
+  if (!ep.addend) {
+    const int M1 = split_rows(M, N);
+    if (M1 > 0) {
       DenseA256 A1{X, lda};
       if (glu) launch256<true>(A1, W, nullptr, M1, N, K, ep, s); else launch256<false>(A1, W, nullptr, M1, N, K, ep, s);
       GemmEpilogue e2 = ep;
@@ -505,6 +512,16 @@ const char* launch_gemm256_qkrope(const uint16_t* X, int lda, const uint16_t* W,
   GemmEpilogue ep;
   ep.bias = bias;
   DenseA256 A{X, lda};
+  const int M1 = rk.qkv ? split_rows(M, N) : 0;
+  if (M1 > 0) {  // wave quantisation as in launch_gemm256: the trailing rows take the small-tile GEMM + the separate kernel
+    launch256<false, DenseA256, true>(A, W, nullptr, M1, N, K, ep, s, rk);
+    GemmEpilogue e2;
+    e2.out = rk.qkv; e2.ldo = N; e2.bias = bias;  // rk.qkv: fp32 scratch [>= M - M1][N]
+    if (const char* err = launch_gemm16_small(X + (size_t)M1 * lda, lda, W, M - M1, N, K, e2, false, s)) return err;
+    RopeKvArgs r2 = rk;
+    r2.row_seq += M1; r2.row_pos += M1; r2.q16 += (size_t)M1 * rk.n_q * 128;
+    return launch_qknorm_rope_kv(r2, M - M1, false, s);
+  }
   launch256<false, DenseA256, true>(A, W, nullptr, M, N, K, ep, s, rk);
   return nullptr;
 }
