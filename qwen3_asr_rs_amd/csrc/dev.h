@@ -72,6 +72,13 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<0x140>(v);  // row_mirror
   return v;
 }
+// sum over the aligned group of 8 lanes
+__device__ __forceinline__ float row8_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  return v;
+}
 __device__ __forceinline__ float row16_max(float v) {
   v = fmaxf(v, dpp_mov<0xB1>(v));
   v = fmaxf(v, dpp_mov<0x4E>(v));

@@ -95,6 +95,7 @@ void set_thread_error(const std::string& msg) { g_last_error = msg; }  // used b
 static int g_decode_group_size = -1, g_decode_parallel_groups = -1;
 // A/B knob: QK-norm + RoPE + cache append as the qkv GEMM's epilogue in batch-sized prefills (Q3A_FUSE_QKROPE, default on)
 static int g_fuse_qkrope = -1;
+static int g_skinny_q = -1;
 
 struct q3a_engine {
   Dims d;
@@ -498,6 +499,11 @@ struct q3a_engine {
     total_P = off;
     max_new = std::min(std::max(max_new_req, 1), opts.max_new_tokens);
     max_ctx = ((maxP + max_new + 1 + 63) / 64) * 64;
+    {  // A/B knob: extra keys per (sequence, kv head) cache row block, so that the streams of the batched decode attention
+       // do not all start a power of two apart (512 keys x 256 B = 128 KiB)
+      static const int pad = [] { const char* e = getenv("Q3A_CTX_PAD"); return e ? atoi(e) : 0; }();
+      if (pad > 0) max_ctx += (pad + 7) / 8 * 8;
+    }
     ensure_rope(max_ctx + 1);  // argmax_finalize reads the row of the position AFTER the last one the cache can hold
     std::vector<int> ids_v(ids_h, ids_h + total_P);
     std::vector<AttnSeg> segs(b);
@@ -654,7 +660,13 @@ struct q3a_engine {
   // o / down projection) also leaves it pre-normalised for the GEMM that reads it next -- bf16(x * w_norm) in MFMA
   // fragment order in nn_x plus partial sums of x^2 in nn_ss (kernels.h NextNormOut / SkinnyArgs::xw16f).
   bool prenorm_path() const { return B > kGemvMaxSeq && !precise(); }
-  int nn_parts() const { return d.hidden / 16; }  // one partial per 16-column block of a hidden-wide GEMM output
+  // o / down projections of the batched decode step as 8-row x 16-sequence workgroups (k_skinny.hip QS; Q3A_SKINNY_Q=0: off)
+  bool skinny_q() const {
+    if (g_skinny_q < 0) { const char* e = getenv("Q3A_SKINNY_Q"); g_skinny_q = e ? atoi(e) : 1; }
+    auto whole = [](int K) { const int st = K / 32, per = (st + 7) / 8, unr = per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 12; return K % 256 == 0 && per % unr == 0; };
+    return g_skinny_q != 0 && !precise() && d.hidden % 64 == 0 && whole(d.q_dim()) && whole(d.inter);
+  }
+  int nn_parts() const { return d.hidden / (skinny_q() ? 8 : 16); }  // one partial per 16- (8-) column block of a hidden-wide GEMM output
   // Batched decode (more than kGemvMaxSeq sequences) runs in groups of <= 32 sequences: the skinny MFMA GEMM holds 32
   // sequences per weight sweep, and the second group's sweep of a 4-13 MB matrix is served by the L2 / Infinity Cache.
   int n_groups(int b) const { return b <= kGemvMaxSeq ? 1 : (b + gsize - 1) / gsize; }
@@ -754,6 +766,7 @@ struct q3a_engine {
     o.x = s_ctx_g(grp); o.x16 = b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr; o.x16_frag = b16; o.ldx = QD; o.S = S; o.W = wh(l.o_w); o.N = H; o.K = QD;
     o.bias = o_bias ? wf(l.o_b) : nullptr; o.mode = 1; o.out = x; o.ldo = H; o.resid = x;
     if (pre) { o.next_w = wf(l.post_ln); o.next_xw16f = nn_x_g(grp); o.next_ss = nn_ss_g(grp); }
+    o.qsplit = b16 && skinny_q();
     timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { KCHK(launch_skinny(o, precise(), ks)); });
     SkinnyArgs u{};
     u.x = x; u.ldx = H; u.S = S; u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
@@ -764,6 +777,7 @@ struct q3a_engine {
     SkinnyArgs dn{};
     dn.x = s_act_g(grp); dn.x16 = b16 ? reinterpret_cast<uint16_t*>(s_act_g(grp)) : nullptr; dn.x16_frag = b16; dn.ldx = I; dn.S = S; dn.W = wh(l.down_w); dn.N = H; dn.K = I;
     dn.bias = mlp_bias ? wf(l.down_b) : nullptr; dn.mode = 1; dn.out = x; dn.ldo = H; dn.resid = x;
+    dn.qsplit = b16 && skinny_q();
     if (pre && li + 1 < d.dec_layers) {  // (the last layer feeds the final norm + lm_head, which read x_dec)
       dn.next_w = wf(L.dec[li + 1].in_ln); dn.next_xw16f = nn_x_g(grp); dn.next_ss = nn_ss_g(grp);
     }
@@ -1308,6 +1322,7 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (strcmp(key, "decode_group_size") == 0) { g_decode_group_size = value; return 0; }
   if (strcmp(key, "decode_parallel_groups") == 0) { g_decode_parallel_groups = value; return 0; }
   if (strcmp(key, "fuse_qkrope") == 0) { g_fuse_qkrope = value; return 0; }
+  if (strcmp(key, "skinny_q") == 0) { g_skinny_q = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";
   return 1;
 }

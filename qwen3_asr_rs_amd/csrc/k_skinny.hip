@@ -61,16 +61,30 @@ __device__ __forceinline__ float sq4(const float4& a) { return a.x * a.x + a.y *
 // cache lines per wave instruction instead of the 16 of a direct fragment load, which the L1 retires twice as fast
 // -- into a wave-private region (no barrier: the wave waits for its own DMA), swizzled like k_gemm16.hip so that the
 // fragment reads (ds_read_b128, 16 rows x 16 B) are conflict-free.  The wave slice is consumed in passes of UNR steps (one pass when UNR == K/32/8).
-template <bool SPLIT, int TILES, int SH, int XMODE, int UNR, bool WLDS>
+// QS ("quarter" workgroups, hidden-wide outputs only): a workgroup owns 8 weight rows x ONE 16-sequence half.  At N = 1024
+// the 16-row x 32-sequence shape gives 64 workgroups, each pulling its 64-96 KB weight slab AND the whole 128-192 KB
+// activation matrix through one CU's L1 (the measured bound of these kernels) while 192 CUs idle; 256 quarter workgroups
+// move half the bytes each.  The two halves of a row tile sit 8 apart in dispatch order (same XCD): the second weight
+// read is an L2 hit, so the weight stream uses the default cache policy here instead of nt.
+template <bool SPLIT, int TILES, int SH, int XMODE, int UNR, bool WLDS, bool QS = false>
 __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   static_assert(!(SPLIT && XMODE >= 2), "the precise mode keeps fp32 activations");
   static_assert(!WLDS || UNR % 2 == 0, "the LDS image is made of 64-wide k columns");
+  static_assert(!QS || (TILES == 1 && SH == 1 && XMODE == 2 && WLDS), "quarter workgroups: bf16 fragment-order x, LDS-staged weights");
+  constexpr int PIECES = QS ? 1 : 2;  // 8-row x 128-B DMA pieces per (tile, 64-wide k column)
   extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];  // WLDS: [wave][tile][UNR/2 columns][16 rows][128 B]
   __shared__ float part[SK_WAVES][TILES][SH][16][17];  // [k-slice][tile][seq half][row][sequence] (+1 pad)
   __shared__ float ssp[SK_WAVES][SH][16];              // XMODE 1: sum(x^2) of each sequence over the wave's K slice
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kc = lane >> 4;  // row / sequence inside the fragment, k-chunk (8 elements)
-  const int n0 = blockIdx.x * 16 * TILES;
+  int n0 = blockIdx.x * 16 * TILES, hsel = 0, part_row = blockIdx.x;
+  if (QS) {  // block b: XCD b & 7; consecutive same-XCD blocks alternate the sequence half
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    hsel = j % a.qs_halves;
+    part_row = (j / a.qs_halves) * 8 + xcd;
+    n0 = part_row * 8;
+  }
+  const int lrow = QS ? (l15 & 7) : l15;  // fragment row -> weight row of the tile (QS: rows 8..15 duplicate 0..7, discarded)
   const int K = a.K;
   const int steps = K / 32, per = (steps + SK_WAVES - 1) / SK_WAVES;
   const int ks0 = wave * per, ks1 = min(steps, ks0 + per);
@@ -83,14 +97,14 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   const uint16_t* wrow[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
-    const int row = n0 + t * 16 + l15;
+    const int row = n0 + t * 16 + lrow;
     wrow[t] = a.W + (size_t)(row < a.N ? row : a.N - 1) * K + kc * kcw;
   }
   const float* xrow[SH];
   const uint16_t* xrow16[SH];
 #pragma unroll
   for (int h = 0; h < SH; ++h) {
-    const int s = h * 16 + l15;
+    const int s = (QS ? hsel : h) * 16 + l15;
     const size_t off = (size_t)(s < a.S ? s : a.S - 1) * a.ldx + kc * kcw;
     xrow[h] = a.x + off;
     xrow16[h] = a.x16 + off;
@@ -105,7 +119,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int h = 0; h < SH; ++h) acc[t][h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  unsigned char* const wbase = wlds + (size_t)wave * (TILES * (UNR / 2) * 2048);
+  unsigned char* const wbase = wlds + (size_t)wave * (TILES * (UNR / 2) * PIECES * 1024);
   for (int kb = ks0; kb < ks1; kb += UNR) {
     uint4 wv[WLDS ? 1 : UNR][TILES];
     float4 x0[UNR][SH], x1[UNR][SH], w0[UNR], w1[UNR];
@@ -118,10 +132,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
         for (int col = 0; col < UNR / 2; ++col)
 #pragma unroll
-          for (int g = 0; g < 2; ++g) {
+          for (int g = 0; g < PIECES; ++g) {
             const int r16 = g * 8 + rr, row = n0 + t * 16 + r16;
             const uint16_t* src = a.W + (size_t)(row < a.N ? row : a.N - 1) * K + (size_t)kb * 32 + col * 64 + (p ^ ((r16 >> 1) & 7)) * 8;
-            __builtin_amdgcn_global_load_lds((sk_gptr_t)src, (sk_lptr_t)(wbase + ((t * (UNR / 2) + col) * 2 + g) * 1024), 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((sk_gptr_t)src, (sk_lptr_t)(wbase + ((t * (UNR / 2) + col) * PIECES + g) * 1024), 16, 0, QS ? 0 : 2);
           }
     }
 #pragma unroll
@@ -142,13 +156,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
       for (int h = 0; h < SH; ++h) {
         if (XMODE == 3) {  // pre-normalised x * w_norm, always in fragment order
-          xq[u][h] = *reinterpret_cast<const uint4*>(a.xw16f + ((((size_t)ks * 2 + h) * 4 + kc) * 16 + l15) * 8);
+          xq[u][h] = *reinterpret_cast<const uint4*>(a.xw16f + ((((size_t)ks * 2 + (QS ? hsel : h)) * 4 + kc) * 16 + l15) * 8);
         } else if (XMODE == 2) {
 #if (Q3A_SK_EXP & 1)
           xq[u][h] = make_uint4(ks, lane, 0u, 0u);
 #else
           // fragment order (kernels.h skinny_frag_index): lane-linear, 1 KiB contiguous per (k-step, sequence half)
-          const uint16_t* xp = a.x16_frag ? a.x16 + ((((size_t)ks * 2 + h) * 4 + kc) * 16 + l15) * 8 : xrow16[h] + ko;
+          const uint16_t* xp = a.x16_frag ? a.x16 + ((((size_t)ks * 2 + (QS ? hsel : h)) * 4 + kc) * 16 + l15) * 8 : xrow16[h] + ko;
           xq[u][h] = *reinterpret_cast<const uint4*>(xp);
 #endif
         } else {
@@ -183,8 +197,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
           const bf16x8_t wf = WLDS
-              ? *reinterpret_cast<const bf16x8_t*>(wbase + (t * (UNR / 2) + (u >> 1)) * 2048 + l15 * 128 +
-                                                   ((((u & 1) * 4 + kc) ^ ((l15 >> 1) & 7)) * 16))
+              ? *reinterpret_cast<const bf16x8_t*>(wbase + (t * (UNR / 2) + (u >> 1)) * (PIECES * 1024) + lrow * 128 +
+                                                   ((((u & 1) * 4 + kc) ^ ((lrow >> 1) & 7)) * 16))
               : *reinterpret_cast<const bf16x8_t*>(&wv[WLDS ? 0 : u][t]);
           acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hi, acc[t][h], 0, 0, 0);
           if (SPLIT) acc[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, lo, acc[t][h], 0, 0, 0);
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int h = 0; h < SH; ++h) {
       float q = 0.f;
-      for (int p = wave * 4 + kc; p < a.ss_nparts; p += SK_WAVES * 4) q += a.ss_parts[(size_t)p * 32 + h * 16 + l15];
+      for (int p = wave * 4 + kc; p < a.ss_nparts; p += SK_WAVES * 4) q += a.ss_parts[(size_t)p * 32 + (QS ? hsel : h) * 16 + l15];
       ss[h] = q;
     }
   }
@@ -226,9 +240,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   // ---- fixed-order reduction of the K-slices + epilogue: thread -> (row i, sequence s) ----
   // 16 rows x 32 sequences = 512 threads; 16 consecutive lanes own the 16 consecutive output columns of one sequence
   // (64-B runs; with the sequence as the fast index every lane hit its own line: 4 KB stride)
-  const int i = tid & 15, s = tid >> 4;
-  const bool live_s = s < a.S && (SH == 2 || s < 16);  // (no early return: the row reduction below needs whole rows)
-  const int sh = (SH == 1 || !live_s) ? 0 : s >> 4, sj = s & 15;
+  // (QS: 8 rows x 16 sequences = the first 128 threads, 8 consecutive lanes per sequence)
+  const int i = QS ? (tid & 7) : (tid & 15), s = QS ? hsel * 16 + ((tid >> 3) & 15) : (tid >> 4);
+  const bool live_s = QS ? (tid < 128 && s < a.S) : (s < a.S && (SH == 2 || s < 16));  // (no early return: the row reduction below needs whole rows)
+  const int sh = (QS || SH == 1 || !live_s) ? 0 : s >> 4, sj = s & 15;
   float v[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
@@ -256,8 +271,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     }
     if (a.mode == 1 && a.next_w) {  // hand the new residual row to the next GEMM pre-normalised (kernels.h)
       if (ok) a.next_xw16f[skinny_frag_index(s, n)] = (uint16_t)f32_to_bf16_bits(y * a.next_w[n]);
-      const float q = row16_sum(y * y);  // this block's 16 columns of sequence s
-      if (i == 0 && live_s) a.next_ss[(size_t)blockIdx.x * 32 + s] = q;
+      const float q = QS ? row8_sum(y * y) : row16_sum(y * y);  // this block's 16 (8) columns of sequence s
+      if (i == 0 && live_s) a.next_ss[(size_t)part_row * 32 + s] = q;
     }
   } else {  // rows n0..n0+15 = gate, n0+16..n0+31 = up of logical rows n0/2 .. n0/2+15
     if (!live_s || n0 + 16 + i >= a.N) return;
@@ -294,6 +309,15 @@ void launch_k(const SkinnyArgs& a, dim3 grid, hipStream_t s) {
 }
 template <bool SPLIT, int XMODE, int UNR>
 void launch_u(const SkinnyArgs& a, hipStream_t s) {
+  if constexpr (!SPLIT && XMODE == 2 && UNR % 2 == 0) {
+    if (a.qsplit) {  // validated by launch_skinny: mode 1, fragment-order x, N % 64 == 0, whole passes of UNR steps
+      SkinnyArgs q = a;
+      q.qs_halves = a.S > 16 ? 2 : 1;
+      const dim3 grid((a.N / 8) * q.qs_halves), block(SK_WAVES * 64);
+      hipLaunchKernelGGL((skinny_kernel<false, 1, 1, 2, UNR, true, true>), grid, block, (size_t)SK_WAVES * (UNR / 2) * 1024, s, q);
+      return;
+    }
+  }
   if (a.mode == 2) {
     const dim3 grid((a.N + 31) / 32);
     if (a.S <= 16) launch_k<SPLIT, 2, 1, XMODE, UNR>(a, grid, s); else launch_k<SPLIT, 2, 2, XMODE, UNR>(a, grid, s);
@@ -307,7 +331,7 @@ void launch_s(const SkinnyArgs& a, hipStream_t s) {
   const int per = (a.K / 32 + SK_WAVES - 1) / SK_WAVES;  // k-steps per wave
   // registers per step and lane: 4 (W) x tiles + 4 (bf16 x) or 8..16 (fp32 x [+ norm weight]) x sequence halves
   if constexpr (XMODE >= 2) {
-    if (per <= 4) launch_u<SPLIT, XMODE, 4>(a, s); else if (per <= 8) launch_u<SPLIT, XMODE, 8>(a, s); else launch_u<SPLIT, XMODE, 12>(a, s);
+    if (per <= 2) launch_u<SPLIT, XMODE, 2>(a, s); else if (per <= 4) launch_u<SPLIT, XMODE, 4>(a, s); else if (per <= 8) launch_u<SPLIT, XMODE, 8>(a, s); else launch_u<SPLIT, XMODE, 12>(a, s);
   } else {
     if (per <= 4) launch_u<SPLIT, XMODE, 4>(a, s); else launch_u<SPLIT, XMODE, 6>(a, s);
   }
@@ -331,7 +355,9 @@ hipError_t allow_big_lds_shapes() {
 
 // Once per device, outside any stream capture: the LDS-staged variants use up to 150 KiB of dynamic LDS.
 const char* skinny_init() {
-  hipError_t e = allow_big_lds_shapes<2, 4>();
+  hipError_t e = allow_big_lds_shapes<2, 2>();
+  if (e == hipSuccess) e = allow_big_lds_shapes<3, 2>();
+  if (e == hipSuccess) e = allow_big_lds_shapes<2, 4>();
   if (e == hipSuccess) e = allow_big_lds_shapes<2, 8>();
   if (e == hipSuccess) e = allow_big_lds_shapes<2, 12>();
   if (e == hipSuccess) e = allow_big_lds_shapes<3, 4>();
@@ -353,6 +379,11 @@ const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s) {
   if (a.x16 && (split || a.rms_w)) return "skinny gemm: bf16 x excludes the precise mode and the fused RMSNorm";
   if (a.xw16f && (split || a.rms_w || a.x16 || !a.ss_parts || a.ss_nparts <= 0)) return "skinny gemm: pre-normalised input is exclusive and needs its partial sums";
   if (a.next_w && (a.mode != 1 || !a.next_xw16f || !a.next_ss)) return "skinny gemm: next-norm output needs mode 1 and both buffers";
+  if (a.qsplit) {
+    const int per = (a.K / 32 + SK_WAVES - 1) / SK_WAVES, unr = per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 12;
+    if (split || a.mode != 1 || !a.x16 || !a.x16_frag || a.N % 64 != 0 || (a.K / 32) % SK_WAVES != 0 || per % unr != 0)
+      return "skinny gemm: quarter workgroups need mode 1, bf16 fragment-order x, N % 64 == 0 and K % (256 * 2|4|8|12) == 0";
+  }
   if (a.xw16f) launch_s<false, 3>(a, s);
   else if (a.x16) launch_s<false, 2>(a, s);
   else if (a.rms_w) { if (split) launch_s<true, 1>(a, s); else launch_s<false, 1>(a, s); }

@@ -170,6 +170,10 @@ struct SkinnyArgs {
   // mode 1 only, producer side of the above for the NEXT GEMM (null: off): after out = resid + y is stored,
   // next_xw16f[frag(s, n)] = bf16(out * next_w[n]) and next_ss[blockIdx.x][s] = sum over the block's 16 columns of out^2
   const float* next_w; uint16_t* next_xw16f; float* next_ss;
+  // mode 1, bf16 fragment-order x, N % 64 == 0: "quarter" workgroups of 8 rows x 16 sequences (k_skinny.hip); next_ss then has
+  // N / 8 partial rows instead of N / 16 -- the caller sizes its buffers and the consumer's ss_nparts accordingly
+  int qsplit;
+  int qs_halves;  // (set by the launcher: 16-sequence halves per row tile)
 };
 // the same producer duty for kernels that write a whole row of the residual stream (token embedding)
 struct NextNormOut {

@@ -205,6 +205,35 @@ def test_fused_qknorm_rope_epilogue_of_the_qkv_gemm(tiny_dir, tiny_untied_dir):
         lib.q3a_debug_set(b"fuse_qkrope", 1)
 
 
+def test_quarter_workgroup_skinny_gemm_matches_full_tiles(tiny_dir):
+    """Batched decode step: the o / down projections as 8-row x 16-sequence workgroups (default) against the 16-row x
+    32-sequence shape on the same inputs -- same K slices and reduction order per output, only the RMSNorm partial sums
+    are grouped differently -- for a full group (32 = two sequence halves), a short group (8) and 16 < S < 32."""
+    from qwen3_asr_rs_amd import _lib
+    lib = _lib.load()
+    clips = [synthetic.synthetic_clip(80 + i, 1.0 + 0.11 * (i % 7)) for i in range(40)]
+    try:
+        for n in (40, 21):
+            got = {}
+            for q in (1, 0):
+                assert lib.q3a_debug_set(b"skinny_q", q) == 0
+                eng = HipEngine(tiny_dir, 0, max_new_tokens=8)
+                eng.mel(clips[:n])
+                eng.encode()
+                prompts = [HipEngine.build_prompt(eng.num_audio_tokens(len(c))) for c in clips[:n]]
+                eng.prefill(prompts)
+                eng.set_next_tokens([7 + i for i in range(n)])
+                lg1, _, _ = eng.decode_step()
+                lg2, _, _ = eng.decode_step()
+                got[q] = np.concatenate([lg1.ravel(), lg2.ravel()])
+                eng.close()
+            assert rel_l2(got[1], got[0]) <= 1e-5
+        assert lib.q3a_debug_set(b"skinny_q", 1) == 0
+        _stage_check(tiny_dir, clips[:9], False, steps=3)
+    finally:
+        lib.q3a_debug_set(b"skinny_q", 1)
+
+
 def test_mfma_attention_matches_valu_attention(tiny_dir):
     """Default mode: the MFMA flash-attention kernels against the fp32 VALU kernels on the same inputs
     (two windows in the encoder, ragged causal prefill)."""
