@@ -119,6 +119,29 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int h = 0; h < SH; ++h) acc[t][h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // epilogue duty of this thread (row i, sequence s) and the operands it will add there: requested now, not after the
+  // reduction barrier (an L2 round trip on the tail of a 5 us kernel)
+  const int ep_i = QS ? (tid & 7) : (tid & 15), ep_s = QS ? hsel * 16 + ((tid >> 3) & 15) : (tid >> 4);
+  const bool ep_live = QS ? (tid < 128 && ep_s < a.S) : (ep_s < a.S && (SH == 2 || ep_s < 16));
+  float ep_resid = 0.f, ep_bias = 0.f, ep_nw = 0.f;
+  if (TILES == 1 && ep_live && n0 + ep_i < a.N) {
+    if (a.mode == 1) ep_resid = a.resid[(size_t)ep_s * a.ldo + n0 + ep_i];
+    if (a.bias) ep_bias = a.bias[n0 + ep_i];
+    if (a.mode == 1 && a.next_w) ep_nw = a.next_w[n0 + ep_i];
+  }
+  // XMODE 3: this lane's share of the producer's sum(x^2) partial rows (p = wave*4 + kc, then every 32nd): the first SS_PRE
+  // of them are requested here, in front of the weight stream, so their L2 round trip is not on the tail of the kernel
+  constexpr int SS_PRE = 4;  // covers 128 partial rows (hidden 1024 in 8-column blocks)
+  float ssq[SH][SS_PRE];
+  if (XMODE == 3) {
+#pragma unroll
+    for (int h = 0; h < SH; ++h)
+#pragma unroll
+      for (int j = 0; j < SS_PRE; ++j) {
+        const int p = wave * 4 + kc + j * SK_WAVES * 4;
+        ssq[h][j] = p < a.ss_nparts ? a.ss_parts[(size_t)p * 32 + (QS ? hsel : h) * 16 + l15] : 0.f;
+      }
+  }
   unsigned char* const wbase = wlds + (size_t)wave * (TILES * (UNR / 2) * PIECES * 1024);
   for (int kb = ks0; kb < ks1; kb += UNR) {
     uint4 wv[WLDS ? 1 : UNR][TILES];
@@ -220,11 +243,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     for (int h = 0; h < SH; ++h)
 #pragma unroll
       for (int r = 0; r < 4; ++r) part[wave][t][h][kc * 4 + r][l15] = acc[t][h][r];
-  if (XMODE == 3) {  // sum(x^2) comes from the producer's partials: this lane adds its share of the ss_nparts rows
+  if (XMODE == 3) {  // sum(x^2) comes from the producer's partials (requested before the K loop, see there)
 #pragma unroll
     for (int h = 0; h < SH; ++h) {
       float q = 0.f;
-      for (int p = wave * 4 + kc; p < a.ss_nparts; p += SK_WAVES * 4) q += a.ss_parts[(size_t)p * 32 + (QS ? hsel : h) * 16 + l15];
+#pragma unroll
+      for (int j = 0; j < SS_PRE; ++j) q += ssq[h][j];
+      for (int p = wave * 4 + kc + SS_PRE * SK_WAVES * 4; p < a.ss_nparts; p += SK_WAVES * 4) q += a.ss_parts[(size_t)p * 32 + (QS ? hsel : h) * 16 + l15];
       ss[h] = q;
     }
   }
@@ -241,8 +266,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   // 16 rows x 32 sequences = 512 threads; 16 consecutive lanes own the 16 consecutive output columns of one sequence
   // (64-B runs; with the sequence as the fast index every lane hit its own line: 4 KB stride)
   // (QS: 8 rows x 16 sequences = the first 128 threads, 8 consecutive lanes per sequence)
-  const int i = QS ? (tid & 7) : (tid & 15), s = QS ? hsel * 16 + ((tid >> 3) & 15) : (tid >> 4);
-  const bool live_s = QS ? (tid < 128 && s < a.S) : (s < a.S && (SH == 2 || s < 16));  // (no early return: the row reduction below needs whole rows)
+  const int i = ep_i, s = ep_s;
+  const bool live_s = ep_live;  // (no early return: the row reduction below needs whole rows)
   const int sh = (QS || SH == 1 || !live_s) ? 0 : s >> 4, sj = s & 15;
   float v[TILES];
 #pragma unroll
@@ -265,12 +290,12 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     float y = 0.f;
     if (ok) {
       y = v[0];
-      if (a.bias) y += a.bias[n];
-      if (a.mode == 1) y += a.resid[(size_t)s * a.ldo + n];
+      if (a.bias) y += ep_bias;
+      if (a.mode == 1) y += ep_resid;
       a.out[(size_t)s * a.ldo + n] = y;
     }
     if (a.mode == 1 && a.next_w) {  // hand the new residual row to the next GEMM pre-normalised (kernels.h)
-      if (ok) a.next_xw16f[skinny_frag_index(s, n)] = (uint16_t)f32_to_bf16_bits(y * a.next_w[n]);
+      if (ok) a.next_xw16f[skinny_frag_index(s, n)] = (uint16_t)f32_to_bf16_bits(y * ep_nw);
       const float q = QS ? row8_sum(y * y) : row16_sum(y * y);  // this block's 16 (8) columns of sequence s
       if (i == 0 && live_s) a.next_ss[(size_t)part_row * 32 + s] = q;
     }
