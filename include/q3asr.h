@@ -230,7 +230,11 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *   "dattn_batched_min_wgs"  sequences x kv heads of a decode group from which the batched decode step uses the
  *                        one-workgroup-per-(sequence, kv head) attention kernel (k_dattn.hip) instead of key splits + merge.
  *   "decode_group_size"  sequences per group of the batched decode step (1..32; 0 = 32), taken at the next prefill.
- *   "decode_parallel_groups"  1: groups run as parallel stream / hipGraph branches (default), 0: one after the other. */
+ *   "decode_parallel_groups"  1: groups run as parallel stream / hipGraph branches (default), 0: one after the other.
+ *   "fuse_qkrope"        1 (default): batch-sized prefills run QK-norm + RoPE + the KV-cache append as the epilogue of the qkv
+ *                        GEMM; 0: as the separate kernel (taken at the next prefill).
+ *   "skinny_q"           1 (default): o / down projections of the batched decode step as 8-row x 16-sequence workgroups;
+ *                        0: 16 rows x 32 sequences (taken at the next engine / batch set-up: it sizes a buffer). */
 int32_t q3a_debug_set(const char* key, int32_t value);
 
 /* Kernel self-tests against naive device references (no model needed): returns max abs error. */
