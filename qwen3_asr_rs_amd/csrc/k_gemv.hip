@@ -247,12 +247,8 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int g, const in
 // that workgroups b, b + G, b + 2G .. of the next GEMV will stream (G = this grid, a multiple of 8: same XCD, same L2).
 // It never touches a barrier-protected resource; in the ATTN variant it joins the workgroup's single barrier so the
 // barrier count of the other waves stays whole.
-// The requests are LDS-DMA loads into a 1 KiB sink nobody reads: a VGPR destination would have to stay untouched until the
-// data lands, which plain C cannot promise for an asm load the compiler does not know to be asynchronous (a first version
-// re-used the destination pair for the next address and faulted).
-__device__ __forceinline__ void gemv_prefetch_wave(const GemvArgs::Prefetch& p, int lane, void* sink) {
-  typedef const void __attribute__((address_space(1)))* gptr_t;
-  typedef void __attribute__((address_space(3)))* lptr_t;
+__device__ __forceinline__ void gemv_prefetch_wave(const GemvArgs::Prefetch& p, int lane) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   const size_t row_bytes = (size_t)p.K * 2;
   const int nseg = p.glu ? 2 : 1, rows = p.glu ? p.rows_per_wg / 2 : p.rows_per_wg;
   for (int bp = blockIdx.x; bp < p.n_wg; bp += gridDim.x) {
@@ -262,9 +258,9 @@ __device__ __forceinline__ void gemv_prefetch_wave(const GemvArgs::Prefetch& p, 
       if (row0 + rows > p.N) continue;
       const char* base = reinterpret_cast<const char*>(p.W) + (size_t)row0 * row_bytes;
       const size_t len = (size_t)rows * row_bytes;
-      for (size_t off = 0; off < len; off += 1024) {  // (row bytes are multiples of 1 KiB for K % 512 == 0; the tail is clamped)
-        const size_t o = off + (size_t)lane * 16;
-        __builtin_amdgcn_global_load_lds((gptr_t)(base + (o < len ? o : len - 16)), (lptr_t)sink, 16, 0, 0);
+      for (size_t off = (size_t)lane * 16; off < len; off += 1024) {
+        u32x4 sink;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(base + off) : "memory");
       }
     }
   }
@@ -275,12 +271,11 @@ __global__ __launch_bounds__(320) void gemv1_kernel(GemvArgs a) {
   __shared__ float am_v[4][1];
   __shared__ int am_i[4][1];
   __shared__ __attribute__((aligned(16))) float x_s[ATTN ? KI * 512 : 4];  // only the attention merge goes through LDS
-  __shared__ __attribute__((aligned(16))) uint4 pf_sink[64];                // write-only target of the prefetch wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
-  if (__builtin_amdgcn_readfirstlane(wave) == 4) {  // (wave-uniform branch) only in a 320-thread launch: a.pf.W set, not mode 3
+  if (wave == 4) {  // only in a 320-thread launch (a.pf.W set, not mode 3)
     __builtin_amdgcn_s_sleep(8);  // let the four streaming waves put their own requests in the queues first
-    gemv_prefetch_wave(a.pf, lane, pf_sink);
+    gemv_prefetch_wave(a.pf, lane);
     if (ATTN) asm volatile("s_barrier" ::: "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
