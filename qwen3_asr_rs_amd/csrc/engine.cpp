@@ -96,8 +96,6 @@ static int g_decode_group_size = -1, g_decode_parallel_groups = -1;
 // A/B knob: QK-norm + RoPE + cache append as the qkv GEMM's epilogue in batch-sized prefills (Q3A_FUSE_QKROPE, default on)
 static int g_fuse_qkrope = -1;
 static int g_skinny_q = -1;
-// A/B knob: one-sequence decode GEMVs carry a fifth wave that requests the next GEMV's weight rows (Q3A_GEMV_PREFETCH)
-static int g_gemv_prefetch = -1;
 
 struct q3a_engine {
   Dims d;
@@ -723,13 +721,6 @@ struct q3a_engine {
       GemvArgs g{};
       g.x = x; g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
       g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = qkv; g.ldo = QKV;
-      if (g_gemv_prefetch < 0) { const char* e = getenv("Q3A_GEMV_PREFETCH"); g_gemv_prefetch = e ? atoi(e) : 0; }
-      const bool pf = g_gemv_prefetch != 0 && S == 1;
-      auto next_weights = [&](const uint16_t* W, int N, int K, int mode) {  // what a GEMV over W will stream
-        GemvArgs n{}; n.W = W; n.N = N; n.K = K; n.mode = mode;
-        return gemv_prefetch_of(n);
-      };
-      if (pf) g.pf = next_weights(wh(l.o_w), H, QD, 1);  // (the attention launch in between streams KV only)
       timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, ks)); });
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
       GemvArgs o{};
@@ -742,17 +733,14 @@ struct q3a_engine {
       }
       o.ldx = QD; o.W = wh(l.o_w); o.N = H; o.K = QD; o.bias = o_bias ? wf(l.o_b) : nullptr;
       o.mode = 1; o.out = x; o.ldo = H; o.resid = x;
-      if (pf) o.pf = next_weights(wh(l.gu_w), 2 * I, H, 2);
       timed(Q3A_KC_GEMV_O, 2.0 * H * QD, [&] { KCHK(launch_gemv(o, S, ks)); });
       GemvArgs u{};
       u.x = x; u.ldx = H; u.rms_w = wf(l.post_ln); u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
       u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act_g(grp); u.ldo = I;
-      if (pf) u.pf = next_weights(wh(l.down_w), H, I, 1);
       timed(Q3A_KC_GEMV, 4.0 * I * H, [&] { KCHK(launch_gemv(u, S, ks)); });
       GemvArgs dn{};
       dn.x = s_act_g(grp); dn.ldx = I; dn.W = wh(l.down_w); dn.N = H; dn.K = I; dn.bias = mlp_bias ? wf(l.down_b) : nullptr;
       dn.mode = 1; dn.out = x; dn.ldo = H; dn.resid = x;
-      if (pf && li + 1 < d.dec_layers) dn.pf = next_weights(wh(L.dec[li + 1].qkv_w), QKV, H, 0);
       timed(Q3A_KC_GEMV_DOWN, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, ks)); });
       return;
     }
@@ -1335,7 +1323,6 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (strcmp(key, "decode_parallel_groups") == 0) { g_decode_parallel_groups = value; return 0; }
   if (strcmp(key, "fuse_qkrope") == 0) { g_fuse_qkrope = value; return 0; }
   if (strcmp(key, "skinny_q") == 0) { g_skinny_q = value; return 0; }
-  if (strcmp(key, "gemv_prefetch") == 0) { g_gemv_prefetch = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";
   return 1;
 }

@@ -39,14 +39,6 @@ int gemv_blocks(const GemvArgs& a) {
   return (logical + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
 }
 
-GemvArgs::Prefetch gemv_prefetch_of(const GemvArgs& next) {
-  GemvArgs::Prefetch p{};
-  p.W = next.W; p.K = next.K; p.N = next.N; p.glu = next.mode == 2 ? 1 : 0;
-  p.rows_per_wg = 4 * gemv_rows_per_wave(next);  // physical rows of one workgroup (GLU: half gate, half up)
-  p.n_wg = gemv_blocks(next);
-  return p;
-}
-
 namespace {
 
 // Flash-decoding merge (o_proj input).  attn_scales: every workgroup first turns the per-split softmax
@@ -243,43 +235,13 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int g, const in
 // load sits under a lane-divergent branch -- out-of-range rows / columns are clamped to valid addresses and voided
 // arithmetically.  (With `row < N ? load : 0` guards hipcc put every weight load into its own exec-masked block with
 // an s_waitcnt vmcnt(0) between them: half of the stream was only requested after the other half had landed.)
-// The prefetch wave (wave 4 of a 320-thread launch): requests, with ordinary cached loads whose data is dropped, the rows
-// that workgroups b, b + G, b + 2G .. of the next GEMV will stream (G = this grid, a multiple of 8: same XCD, same L2).
-// It never touches a barrier-protected resource; in the ATTN variant it joins the workgroup's single barrier so the
-// barrier count of the other waves stays whole.
-__device__ __forceinline__ void gemv_prefetch_wave(const GemvArgs::Prefetch& p, int lane) {
-  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-  const size_t row_bytes = (size_t)p.K * 2;
-  const int nseg = p.glu ? 2 : 1, rows = p.glu ? p.rows_per_wg / 2 : p.rows_per_wg;
-  for (int bp = blockIdx.x; bp < p.n_wg; bp += gridDim.x) {
-    for (int sgm = 0; sgm < nseg; ++sgm) {
-      const int j = bp * rows;  // first logical row of the workgroup
-      const int row0 = p.glu ? (j / 16) * 32 + (j % 16) + sgm * 16 : j;
-      if (row0 + rows > p.N) continue;
-      const char* base = reinterpret_cast<const char*>(p.W) + (size_t)row0 * row_bytes;
-      const size_t len = (size_t)rows * row_bytes;
-      for (size_t off = (size_t)lane * 16; off < len; off += 1024) {
-        u32x4 sink;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(base + off) : "memory");
-      }
-    }
-  }
-}
-
 template <int PR, int KI, bool RMS, bool ATTN>
-__global__ __launch_bounds__(320) void gemv1_kernel(GemvArgs a) {
+__global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   __shared__ float am_v[4][1];
   __shared__ int am_i[4][1];
   __shared__ __attribute__((aligned(16))) float x_s[ATTN ? KI * 512 : 4];  // only the attention merge goes through LDS
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K;
-  if (wave == 4) {  // only in a 320-thread launch (a.pf.W set, not mode 3)
-    __builtin_amdgcn_s_sleep(8);  // let the four streaming waves put their own requests in the queues first
-    gemv_prefetch_wave(a.pf, lane);
-    if (ATTN) asm volatile("s_barrier" ::: "memory");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    return;
-  }
   // (an XCD-contiguous block -> row remap, so that each output line is dirtied in one L2 only, measured 0.6 % slower)
   const int g = blockIdx.x * 4 + wave;
   int prow[PR];
@@ -493,7 +455,7 @@ __global__ __launch_bounds__(256) void gemvn_kernel(GemvArgs a) {
 
 template <int PR, int KI>
 void launch1k(const GemvArgs& a, hipStream_t s) {
-  const dim3 grid(gemv_blocks(a)), block((a.pf.W && a.mode != 3) ? 320 : 256);
+  const dim3 grid(gemv_blocks(a)), block(256);
   if (a.attn_po) hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, true>), grid, block, 0, s, a);
   else if (a.rms_w) hipLaunchKernelGGL((gemv1_kernel<PR, KI, true, false>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, false>), grid, block, 0, s, a);

@@ -144,12 +144,8 @@ struct GemvArgs {
   // (x/ldx ignored; K must equal attn_heads*128)
   const float* attn_pm; const float* attn_pl; const float* attn_po; int attn_nsplit; int attn_heads;
   int attn_fast_exp;            // merge weights with the hardware exponential (default mode) instead of expf
-  // Optional (one sequence only): while this GEMV runs, a fifth wave of every workgroup requests the weight rows that the
-  // NEXT GEMV's workgroups on the same XCD will stream (gemv_prefetch_of(next args)), so that kernel starts on warm caches.
-  struct Prefetch { const uint16_t* W; int K; int N; int rows_per_wg; int glu; int n_wg; } pf;
 };
 const char* launch_gemv(const GemvArgs& a, int NB, hipStream_t s);
-GemvArgs::Prefetch gemv_prefetch_of(const GemvArgs& next);  // what a launch of `next` will read, workgroup by workgroup
 constexpr int GEMV_ATTN_MAX_TABLE = 1024;  // min(NB,4) * heads * nsplit must fit (else merge with launch_attn_combine first)
 int gemv_blocks(const GemvArgs& a);        // grid size launch_gemv uses (= number of argmax partials in mode 3)
 int gemv_rows_per_wave(const GemvArgs& a);
