@@ -19,6 +19,8 @@
 //   * writes an unnormalised partial (m, l, o[128]) per (sequence, head, split).  The consumer (the
 //     o_proj GEMV in k_gemv.hip, or attn_combine_kernel below) merges the splits -- no second launch on
 //     the GEMV path.
+#include <stdlib.h>
+
 #include "dev.h"
 #include "kernels.h"
 
@@ -251,12 +253,12 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
 #ifndef Q3A_DATTN_RING
 #define Q3A_DATTN_RING 2  // tiles in flight per wave (A/B: 2 = one tile ahead 15.3 us per layer at 32 x 500 keys, 3 = 16.6 us)
 #endif
-template <int GROUP, typename KVT>
+template <int GROUP, typename KVT, int TILE = 128, int RING_T = Q3A_DATTN_RING>
 __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(DecodeAttnArgs a) {
   constexpr int DPL = Frag16<KVT>::DPL;
   constexpr int LPK = 128 / DPL;
   constexpr int KPI = 64 / LPK;
-  constexpr int NI = (128 / DA_WAVES) / KPI;
+  constexpr int NI = (TILE / DA_WAVES) / KPI;  // TILE keys per round of the workgroup
   constexpr int KEYS_PER_WAVE = KPI * NI;
   constexpr bool DOT2 = sizeof(KVT) == 2;
   __shared__ float q_s[GROUP][128];
@@ -289,13 +291,13 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   // Register ring of RING tiles: the rows of tiles t+1 .. t+RING-1 are in flight while tile t is consumed (one CU must
   // keep > 100 KB requested to stream its share of HBM bandwidth; with one tile ahead the loop ran at one memory round
   // trip per 128 keys: 15.3 us per layer at 32 sequences x 500 keys against ~10 us of HBM time)
-  constexpr int RING = DOT2 ? Q3A_DATTN_RING : 1;  // (the fp32 cache of the precise mode has twice the registers per tile: no ring there)
-  static_assert(RING >= 1 && RING <= 3, "ring depth");
-  uint4 kr0[NI], vr0[NI], kr1[RING > 1 ? NI : 1], vr1[RING > 1 ? NI : 1], kr2[RING > 2 ? NI : 1], vr2[RING > 2 ? NI : 1];
+  constexpr int RING = DOT2 ? RING_T : 1;  // (the fp32 cache of the precise mode has twice the registers per tile: no ring there)
+  static_assert(RING >= 1 && RING <= 4 && NI >= 1, "ring depth / tile size");
+  uint4 kr0[NI], vr0[NI], kr1[RING > 1 ? NI : 1], vr1[RING > 1 ? NI : 1], kr2[RING > 2 ? NI : 1], vr2[RING > 2 ? NI : 1], kr3[RING > 3 ? NI : 1], vr3[RING > 3 ? NI : 1];
   auto load_tile = [&](int t, uint4 (&kr)[NI], uint4 (&vr)[NI]) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int key = min(t * 128 + key_w + i * KPI, a.max_ctx - 1);  // stale / clamped rows are masked below
+      const int key = min(t * TILE + key_w + i * KPI, a.max_ctx - 1);  // stale / clamped rows are masked below
       kr[i] = ld_stream16(kc + (size_t)key * 128 + sub * DPL);
       vr[i] = ld_stream16(vc + (size_t)key * 128 + sub * DPL);
     }
@@ -303,9 +305,10 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   load_tile(0, kr0, vr0);
   if constexpr (RING > 1) load_tile(1, kr1, vr1);  // unconditional (clamped): nothing here waits for `pos`
   if constexpr (RING > 2) load_tile(2, kr2, vr2);
+  if constexpr (RING > 3) load_tile(3, kr3, vr3);
   __builtin_amdgcn_sched_barrier(0);
   const int pos = a.pos[s];
-  const int n_tiles = pos / 128 + 1;  // tiles that hold at least one key <= pos
+  const int n_tiles = pos / TILE + 1;  // tiles that hold at least one key <= pos
 
   if (wave <= GROUP) {  // per-head RMSNorm + RoPE (as dev.h head_norm_rope)
     const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   }
 
   auto consume = [&](int t, uint4 (&kraw)[NI], uint4 (&vraw)[NI]) {
-    const int key_base = t * 128 + key_w;
+    const int key_base = t * TILE + key_w;
     float sc[NI][GROUP];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -424,6 +427,12 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
       if (t + 2 < n_tiles) {
         consume(t + 2, kr2, vr2);
         if (t + 2 + RING < n_tiles) load_tile(t + 2 + RING, kr2, vr2);
+      }
+    }
+    if constexpr (RING > 3) {
+      if (t + 3 < n_tiles) {
+        consume(t + 3, kr3, vr3);
+        if (t + 3 + RING < n_tiles) load_tile(t + 3 + RING, kr3, vr3);
       }
     }
   }
@@ -533,9 +542,12 @@ const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f
   if (a.out16 && a.out_frag && S > 32) return "decode_attn_batched: fragment order holds at most 32 sequences";
   const int group = a.n_q / a.n_kv;
   dim3 grid(a.n_kv, S), block(DA_WAVES * 64);
+  // A/B knob Q3A_DATTN_TILE64=1: 64-key tiles with a 4-deep register ring (same bytes in flight, steadier request stream)
+  static const bool tile64 = [] { const char* e = getenv("Q3A_DATTN_TILE64"); return e && atoi(e) != 0; }();
 #define Q3A_DAB(G)                                                                                          \
   do {                                                                                                      \
     if (kv_f32) hipLaunchKernelGGL((decode_attn_batched_kernel<G, float>), grid, block, 0, s, a);          \
+    else if (tile64) hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t, 64, 4>), grid, block, 0, s, a); \
     else hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t>), grid, block, 0, s, a);              \
   } while (0)
   if (group == 1) Q3A_DAB(1);
