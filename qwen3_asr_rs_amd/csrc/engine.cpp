@@ -530,7 +530,7 @@ struct q3a_engine {
     if (g_decode_parallel_groups < 0) { const char* e = getenv("Q3A_DECODE_PARALLEL"); g_decode_parallel_groups = e ? atoi(e) : 1; }
     gsize = (g_decode_group_size >= 1 && g_decode_group_size <= 32) ? g_decode_group_size : 32;
     const size_t ng = (size_t)n_groups(b);  // groups of <= gsize sequences of the batched decode step
-    nn_x.ensure(ng * 32 * H * 2); nn_ss.ensure((size_t)ng * nn_ss_stride() * 4);
+    nn_x.ensure(ng * 32 * H * 2); nn_ss.ensure((size_t)ng * (H / 8) * 32 * 4);  // room for the finer (8-column) partial rows whichever shape the knob selects later
     x_dec.ensure((size_t)b * H * 4); next_tok.ensure((size_t)b * 4); forced_tok.ensure((size_t)b * 4);
     out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
     // s_ctx / s_act also hold the bf16 fragment-order copies of the skinny GEMM path: always 32 sequences there

@@ -23,8 +23,6 @@
 namespace q3a {
 namespace {
 
-constexpr int KT = 32;  // keys per tile
-
 template <typename KVT> struct Stage8;  // 8 consecutive head dims of one K/V row -> 8 packed bf16
 template <> struct Stage8<uint16_t> {
   static __device__ __forceinline__ uint4 load(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
@@ -38,10 +36,15 @@ template <> struct Stage8<float> {
   }
 };
 
-template <int HD, int GROUP, bool CAUSAL, typename KVT>
+// KSPLIT = 2 (one-clip prefill: few, long rows): the block's waves are (key half) x (query head) over ONE 32-query tile --
+// a staged tile holds 2 x 32 keys, wave w works on half w / GROUP of it with its own online-softmax state, and the halves
+// are merged through LDS at the end.  Twice the workgroups, half the barrier-separated iterations per workgroup.
+template <int HD, int GROUP, bool CAUSAL, typename KVT, int KSPLIT = 1>
 __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
-  constexpr int QTILES = 4 / GROUP;          // 32-query tiles per block
+  constexpr int QTILES = 4 / (GROUP * KSPLIT);  // 32-query tiles per block
+  static_assert(QTILES >= 1, "4 waves = query tiles x heads of the group x key halves");
   constexpr int QT = 32 * QTILES;            // queries per block
+  constexpr int KT = 32 * KSPLIT;            // keys per staged tile (32 per wave)
   constexpr int KS = HD / 16;                // MFMA k-steps of the QK^T product
   constexpr int DT = HD / 32;                // 32-row tiles of O^T
   constexpr int K_STRIDE = HD + 8;           // bf16 per K row in LDS (16 B pad)
@@ -49,8 +52,11 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
   constexpr int CPR = HD / 8;                // 16-B chunks per K/V row
   constexpr int LOADS = KT * CPR / 256;      // chunks per thread per tile (HD=128: 2, HD=64: 1)
   static_assert(LOADS >= 1, "tile too small");
-  __shared__ __attribute__((aligned(16))) uint16_t k_lds[KT * K_STRIDE];
-  __shared__ __attribute__((aligned(16))) uint16_t vt_lds[HD * V_STRIDE];
+  constexpr int KV_LDS = KT * K_STRIDE + HD * V_STRIDE;                       // bf16 elements of the staged tile
+  constexpr int MERGE_LDS = KSPLIT > 1 ? GROUP * (32 * HD + 64) * 2 : 0;      // fp32 O^T + (m, l) of the second key half, in bf16 units
+  __shared__ __attribute__((aligned(16))) uint16_t lds_all[KV_LDS > MERGE_LDS ? KV_LDS : MERGE_LDS];
+  uint16_t* const k_lds = lds_all;
+  uint16_t* const vt_lds = lds_all + KT * K_STRIDE;
 
   const AttnSeg seg = a.segs[blockIdx.z];
   const int kvh = blockIdx.y;
@@ -58,7 +64,8 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
   if (qb0 >= seg.len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const int g = wave % GROUP, qs = wave / GROUP;
+  const int g = wave % GROUP;
+  const int qs = KSPLIT > 1 ? 0 : wave / GROUP, kh = KSPLIT > 1 ? wave / GROUP : 0;  // query tile / key half of this wave
   const int head = kvh * GROUP + g;
   const int q0 = qb0 + qs * 32;              // first query of this wave
   const int qi = q0 + l31;                   // this lane's query (both halves of the wave hold the same 32 queries)
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
     store_tile();
     __syncthreads();
     if (t + 1 < n_tiles) load_tile(t + 1);
-    const int key0 = t * KT;
+    const int key0 = t * KT + kh * 32;  // first key of this wave's 32 of the staged tile
     if (!wave_has_q || (CAUSAL && key0 > wave_qmax)) continue;
 
     // ---- S^T[key][query] = sum_d K[key][d] Q[query][d] ----
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&k_lds[l31 * K_STRIDE + ks * 16 + half * 8]);
+      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(&k_lds[(kh * 32 + l31) * K_STRIDE + ks * 16 + half * 8]);
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfrag[ks], sacc, 0, 0, 0);
     }
     // lane owns query qi and keys key0 + (r&3) + 8*(r>>2) + 4*half
@@ -193,12 +200,36 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
         // contraction slot (half, e) <-> key 16*kk + 4*half + (e & 3) + 8*(e >> 2): same map as the P registers
         const uint16_t* vrow = &vt_lds[(dt * 32 + l31) * V_STRIDE];
         const int gsw = (dt * 4 + (l31 >> 3)) & 7;  // ((d >> 3) & 7) of this lane's row: the store-side XOR
-        const uint2 lo = *reinterpret_cast<const uint2*>(vrow + (((4 * kk + half) ^ gsw) << 2));
-        const uint2 hi = *reinterpret_cast<const uint2*>(vrow + (((4 * kk + half + 2) ^ gsw) << 2));
+        const uint2 lo = *reinterpret_cast<const uint2*>(vrow + kh * 32 + (((4 * kk + half) ^ gsw) << 2));
+        const uint2 hi = *reinterpret_cast<const uint2*>(vrow + kh * 32 + (((4 * kk + half + 2) ^ gsw) << 2));
         uint4 v;
         v.x = lo.x; v.y = lo.y; v.z = hi.x; v.w = hi.y;
         oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(&v), pfrag[kk], oacc[dt], 0, 0, 0);
       }
+    }
+  }
+  if constexpr (KSPLIT > 1) {
+    // ---- merge the key halves: half 1 parks (m, l, O^T) in LDS (the staged tiles are dead), half 0 folds it in ----
+    __syncthreads();
+    float* const mo = reinterpret_cast<float*>(lds_all) + g * (32 * HD + 64);  // [HD/32][16][64 lanes] O^T, then m[32], l[32]
+    if (kh == 1) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mo[(dt * 16 + r) * 64 + lane] = oacc[dt][r];
+      if (half == 0) { mo[32 * HD + l31] = mrun; mo[32 * HD + 32 + l31] = lrun; }
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    const float m2 = mo[32 * HD + l31], l2 = mo[32 * HD + 32 + l31];
+    const float mn = fmaxf(mrun, m2);
+    if (mn != -INFINITY) {  // (padding queries past the segment see nothing in either half)
+      const float f1 = __expf(mrun - mn), f2 = __expf(m2 - mn);  // exp(-inf) = 0 for a half that saw no key
+      lrun = lrun * f1 + l2 * f2;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = oacc[dt][r] * f1 + mo[(dt * 16 + r) * 64 + lane] * f2;
     }
   }
   // ---- write O[query][d] = O^T / l ----
@@ -223,11 +254,11 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
   }
 }
 
-template <int HD, int GROUP, bool CAUSAL, typename KVT>
+template <int HD, int GROUP, bool CAUSAL, typename KVT, int KSPLIT = 1>
 void launch_f(const AttnArgs& a, hipStream_t s) {
-  constexpr int QT = 32 * (4 / GROUP);
+  constexpr int QT = 32 * (4 / (GROUP * KSPLIT));
   dim3 grid((a.max_len + QT - 1) / QT, a.n_kv_heads, a.n_segs);
-  hipLaunchKernelGGL((fattn_kernel<HD, GROUP, CAUSAL, KVT>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((fattn_kernel<HD, GROUP, CAUSAL, KVT, KSPLIT>), grid, dim3(256), 0, s, a);
 }
 
 }  // namespace
@@ -248,7 +279,11 @@ const char* launch_fattn_prefill(const AttnArgs& a, int group, hipStream_t s) {
   if (a.n_segs <= 0) return nullptr;
   if (a.q_rs % 4 != 0 || a.o_rs % 4 != 0) return "fattn: row strides must be multiples of 4";
   if (a.q16 && a.q_rs % 8 != 0) return "fattn: bf16 q row stride must be a multiple of 8";
+  // key halves per workgroup when the plain shape leaves most CUs without a workgroup (one or a few clips); knob for A/B runs
+  static const int ks_wgs = [] { const char* e = getenv("Q3A_FATTN_KSPLIT_MAX_WGS"); return e ? atoi(e) : 512; }();
+  const long wgs64 = (long)((a.max_len + 63) / 64) * a.n_kv_heads * a.n_segs;
   if (group == 1) launch_f<128, 1, true, uint16_t>(a, s);
+  else if (group == 2 && wgs64 < ks_wgs) launch_f<128, 2, true, uint16_t, 2>(a, s);
   else if (group == 2) launch_f<128, 2, true, uint16_t>(a, s);
   else if (group == 4) launch_f<128, 4, true, uint16_t>(a, s);
   else return "fattn: GQA group must be 1, 2 or 4";
