@@ -280,7 +280,7 @@ const char* launch_fattn_prefill(const AttnArgs& a, int group, hipStream_t s) {
   if (a.q_rs % 4 != 0 || a.o_rs % 4 != 0) return "fattn: row strides must be multiples of 4";
   if (a.q16 && a.q_rs % 8 != 0) return "fattn: bf16 q row stride must be a multiple of 8";
   // key halves per workgroup when the plain shape leaves most CUs without a workgroup (one or a few clips); knob for A/B runs
-  static const int ks_wgs = [] { const char* e = getenv("Q3A_FATTN_KSPLIT_MAX_WGS"); return e ? atoi(e) : 512; }();
+  static const int ks_wgs = [] { const char* e = getenv("Q3A_FATTN_KSPLIT_MAX_WGS"); return e ? atoi(e) : 128; }();  // measured: 1 clip (56 workgroups) 22.6 -> 17.7 us per layer, 8 clips (448) 6.8 -> 7.4 ms prefill
   const long wgs64 = (long)((a.max_len + 63) / 64) * a.n_kv_heads * a.n_segs;
   if (group == 1) launch_f<128, 1, true, uint16_t>(a, s);
   else if (group == 2 && wgs64 < ks_wgs) launch_f<128, 2, true, uint16_t, 2>(a, s);
