@@ -5,7 +5,8 @@
 // block-diagonal mask of src/audio_encoder.rs:172-260 turned into segments) and the causal GQA prefill attention
 // of src/layers.rs:321-335.
 //
-// Workgroup = 4 waves = (4/GROUP) tiles of 32 queries x GROUP query heads sharing one K/V head.  Per 32-key tile:
+// Workgroup = 4 waves = (4/GROUP) tiles of 32 queries x GROUP query heads sharing one K/V head (KSPLIT = 2: one query tile,
+// the waves also split the staged keys in halves -- see the kernel).  Per 32-key tile:
 //   * the block stages K[32][HD] (bf16, rows padded by 16 B) and V^T[HD][32] (bf16) in LDS; the next tile's
 //     global loads are already in flight in registers while the current one is consumed;
 //   * S^T = K . Q^T on v_mfma_f32_32x32x16_bf16 ("swapped" product): a lane then owns ONE query column
