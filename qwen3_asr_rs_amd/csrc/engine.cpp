@@ -96,6 +96,8 @@ static int g_decode_group_size = -1, g_decode_parallel_groups = -1;
 // A/B knob: QK-norm + RoPE + cache append as the qkv GEMM's epilogue in batch-sized prefills (Q3A_FUSE_QKROPE, default on)
 static int g_fuse_qkrope = -1;
 static int g_skinny_q = -1;
+// A/B knob: one-sequence decode runs the qkv projection and the attention splits as one launch (Q3A_FUSE_QKV_ATTN)
+static int g_fuse_qkv_attn = -1;
 
 struct q3a_engine {
   Dims d;
@@ -135,6 +137,7 @@ struct q3a_engine {
   DevBuf rope_cur;  // [B][128] cos|sin row of each sequence's current position (kept by argmax_finalize for decode attention)
   DevBuf enc_ctx16, dec_ctx16;  // opts.valu_attention in the default mode: bf16 copy of the fp32 attention context
   DevBuf dec_q16;
+  DevBuf xcd_sync;  // arrival / departure words of the fused qkv + attention launch (one kv head per XCD)
   DevBuf zero_page;  // 256 B of zeros: padded filter taps of the bf16 implicit-GEMM convolutions read it
   int part_stride = 0, attn_nsplit = 0;
   size_t kv_layer_elems = 0;
@@ -530,6 +533,7 @@ struct q3a_engine {
     if (g_decode_parallel_groups < 0) { const char* e = getenv("Q3A_DECODE_PARALLEL"); g_decode_parallel_groups = e ? atoi(e) : 1; }
     gsize = (g_decode_group_size >= 1 && g_decode_group_size <= 32) ? g_decode_group_size : 32;
     const size_t ng = (size_t)n_groups(b);  // groups of <= gsize sequences of the batched decode step
+    if (!xcd_sync.p) { xcd_sync.ensure(8 * 64 * 4); HIPCHK(hipMemset(xcd_sync.p, 0, 8 * 64 * 4)); }  // (never inside a capture)
     nn_x.ensure(ng * 32 * H * 2); nn_ss.ensure((size_t)ng * (H / 8) * 32 * 4);  // room for the finer (8-column) partial rows whichever shape the knob selects later
     x_dec.ensure((size_t)b * H * 4); next_tok.ensure((size_t)b * 4); forced_tok.ensure((size_t)b * 4);
     out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
@@ -721,8 +725,17 @@ struct q3a_engine {
       GemvArgs g{};
       g.x = x; g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
       g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = qkv; g.ldo = QKV;
-      timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, ks)); });
-      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
+      if (g_fuse_qkv_attn < 0) { const char* e = getenv("Q3A_FUSE_QKV_ATTN"); g_fuse_qkv_attn = e ? atoi(e) : 0; }
+      if (g_fuse_qkv_attn != 0 && S == 1 && d.n_kv == 8 && d.n_q == 16 && (H == 1024 || H == 2048) && attn_nsplit <= 32) {
+        // one kv head per XCD: projection rows and key splits of a head share that XCD's L2 (k_dattn.hip qkv_attn_kernel)
+        QkvFuseArgs fa{};
+        fa.x = x; fa.rms_w = wf(l.in_ln); fa.eps = d.rms_eps; fa.W = wh(l.qkv_w); fa.bias = g.bias; fa.K = H;
+        fa.qkv_out = qkv; fa.sync = xcd_sync.as<unsigned>();
+        timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_qkv_attn(da, fa, kv_f32(), ks)); });
+      } else {
+        timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, ks)); });
+        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
+      }
       GemvArgs o{};
       if (std::min(S, 4) * d.n_q * attn_nsplit <= GEMV_ATTN_MAX_TABLE) {  // merge the key splits inside the o_proj GEMV
         o.attn_pm = da.pm; o.attn_pl = da.pl; o.attn_po = da.po;
@@ -936,7 +949,7 @@ struct q3a_engine {
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
                       &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
                       &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po,
-                      &enc_ctx16, &dec_ctx16, &dec_q16, &zero_page, &rope_cur, &nn_x, &nn_ss};
+                      &enc_ctx16, &dec_ctx16, &dec_q16, &xcd_sync, &zero_page, &rope_cur, &nn_x, &nn_ss};
     for (auto* b : bufs) b->release();
     for (auto& kv : taps) kv.second.release();
     if (own_arena && arena) (void)hipFree(arena);
@@ -1323,6 +1336,7 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (strcmp(key, "decode_parallel_groups") == 0) { g_decode_parallel_groups = value; return 0; }
   if (strcmp(key, "fuse_qkrope") == 0) { g_fuse_qkrope = value; return 0; }
   if (strcmp(key, "skinny_q") == 0) { g_skinny_q = value; return 0; }
+  if (strcmp(key, "fuse_qkv_attn") == 0) { g_fuse_qkv_attn = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";
   return 1;
 }

@@ -21,6 +21,8 @@
 //     the GEMV path.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "dev.h"
 #include "kernels.h"
 
@@ -50,8 +52,15 @@ template <> struct Frag16<float> {
 #endif
 constexpr int DA_WAVES = Q3A_DA_WAVES;  // waves per workgroup; a split is always 128 keys
 
-template <int GROUP, typename KVT>
-__global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnArgs a) {
+// Hooks of the fused qkv-projection + attention launch (qkv_attn_kernel below): `pre` runs before the cache rows are
+// requested (it requests the projection's weight rows: loads return in order, so those land first), `mid` after (it
+// finishes the projection, publishes the rows and waits for the other workgroups of the XCD); only then are the new token's
+// q/k/v rows read.  The plain kernel passes NoHook: the q/k/v rows are requested up front, in front of the cache rows.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+template <int GROUP, typename KVT, class Pre, class Mid>
+__device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const int kvh, const int s, const int sp, Pre pre, Mid mid) {
+  constexpr bool FUSED = !std::is_same<Mid, NoHook>::value;
   constexpr int DPL = Frag16<KVT>::DPL;   // head dims per lane: 8 (bf16) / 4 (f32)
   constexpr int LPK = 128 / DPL;          // lanes per key: 16 / 32
   constexpr int KPI = 64 / LPK;           // keys per load instruction: 4 / 2
@@ -64,7 +73,6 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   __shared__ __attribute__((aligned(16))) KVT v_s[128];
   __shared__ float cm[DA_WAVES][GROUP], cl[DA_WAVES][GROUP];
   __shared__ float co[DA_WAVES][GROUP][128];
-  const int kvh = blockIdx.x, s = blockIdx.y, sp = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPK, kq = lane / LPK;
   const int key_lo = sp * KEYS_PER_SPLIT;
@@ -79,18 +87,22 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
   //    fixed address, written by the previous step's finalize) go first: loads return in order, so q is normalised,
   //    rotated and in LDS while the cache rows are still in flight
   float x1 = 0.f, x2 = 0.f, nw1 = 0.f, nw2 = 0.f, c = 0.f, sn = 0.f;
-  if (wave < GROUP + 2) {  // waves 0..GROUP-1: the q heads, GROUP: k, GROUP+1: v
-    const int r = wave < GROUP ? kvh * GROUP + wave : (wave == GROUP ? a.n_q + kvh : a.n_q + a.n_kv + kvh);
-    x1 = row[r * 128 + lane];
-    x2 = row[r * 128 + lane + 64];
-    if (wave <= GROUP) {
-      const float* nw = wave < GROUP ? a.q_norm : a.k_norm;
-      nw1 = nw[lane];
-      nw2 = nw[lane + 64];
-      c = a.rope_cur[(size_t)s * 128 + lane];
-      sn = a.rope_cur[(size_t)s * 128 + 64 + lane];
+  auto load_rows = [&]() {
+    if (wave < GROUP + 2) {  // waves 0..GROUP-1: the q heads, GROUP: k, GROUP+1: v
+      const int r = wave < GROUP ? kvh * GROUP + wave : (wave == GROUP ? a.n_q + kvh : a.n_q + a.n_kv + kvh);
+      x1 = row[r * 128 + lane];
+      x2 = row[r * 128 + lane + 64];
     }
+  };
+  if (wave <= GROUP) {  // (independent of the projection: requested up front in both forms)
+    const float* nw = wave < GROUP ? a.q_norm : a.k_norm;
+    nw1 = nw[lane];
+    nw2 = nw[lane + 64];
+    c = a.rope_cur[(size_t)s * 128 + lane];
+    sn = a.rope_cur[(size_t)s * 128 + 64 + lane];
   }
+  if constexpr (!FUSED) load_rows();
+  pre();
   // 2. the cache rows, unconditionally (rows at or beyond pos hold stale data and are masked below; the index is
   //    clamped to the allocation)
   const int key_base = key_lo + wave * KEYS_PER_WAVE + kq;
@@ -105,6 +117,10 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
     kraw[i] = *reinterpret_cast<const uint4*>(kc + (size_t)key * 128 + sub * DPL);
     vraw[i] = *reinterpret_cast<const uint4*>(vc + (size_t)key * 128 + sub * DPL);
 #endif
+  }
+  if constexpr (FUSED) {
+    mid();
+    load_rows();
   }
   __builtin_amdgcn_sched_barrier(0);
   const int pos = a.pos[s];
@@ -237,6 +253,126 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
     a.po[pi * 128 + lane] = o0;
     a.po[pi * 128 + lane + 64] = o1;
   }
+}
+
+template <int GROUP, typename KVT>
+__global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnArgs a) {
+  decode_attn_body<GROUP, KVT>(a, blockIdx.x, blockIdx.y, blockIdx.z, NoHook{}, NoHook{});
+}
+
+// ---- one sequence: qkv projection + attention in ONE launch ---------------------------------------------------------------
+// kv head g needs exactly the rows q[GROUP*g .. GROUP*g+GROUP), k[g], v[g] of the projection: (GROUP + 2) * 128 = 512 rows at
+// GROUP = 2.  With 8 kv heads and 256 workgroups, workgroup b works for kv head g = b % 8 -- the 32 workgroups the dispatcher
+// places on XCD g -- and computes 16 of those rows (8 waves x 2 rows, the arithmetic of gemv1_kernel<2, KI, true, false>);
+// workgroups 0 .. nsplit-1 of the XCD are also the key splits of the attention.  The hand-off stays inside the XCD: rows
+// are stored (write-through to that XCD's L2, acknowledged by vmcnt), a counter in the same L2 is bumped with a
+// workgroup-scope RMW, and the split workgroups spin on it: 0.3 us for the barrier + 0.4 us for a 2 KiB hand-off against
+// 1.55 us for a kernel boundary and 3.9 us for the same barrier at agent scope (profiles/r2_cluster_barrier.txt).  The
+// splits request their cache rows BEFORE they wait, so the KV round trip hides behind the projection.  The spin is bounded
+// (a lost arrival would produce a wrong token, never a hung box); the last split to leave re-arms the counters.
+struct QkvFuse {
+  const float* x; const float* rms_w; float eps;   // [K] hidden row of the token, input-norm weight
+  const uint16_t* W; const float* bias; int K;     // [(n_q + 2 n_kv) * 128][K]
+  float* qkv_out;                                   // = DecodeAttnArgs::qkv
+  unsigned* sync;                                   // [8][64] words: [g][0] arrivals, [g][32] departures
+};
+
+__device__ __forceinline__ float qa_dot8(const uint4& w, const float (&x)[8], float s) {  // (k_gemv.hip dot8)
+  f32x2_t a = f32x2_t{bf16lo(w.x), bf16hi(w.x)} * f32x2_t{x[0], x[1]};
+  a += f32x2_t{bf16lo(w.y), bf16hi(w.y)} * f32x2_t{x[2], x[3]};
+  a += f32x2_t{bf16lo(w.z), bf16hi(w.z)} * f32x2_t{x[4], x[5]};
+  a += f32x2_t{bf16lo(w.w), bf16hi(w.w)} * f32x2_t{x[6], x[7]};
+  return s + (a.x + a.y);
+}
+
+template <int GROUP, int KI>
+struct QkvRows {  // the two projection rows of one wave: request(), then finish()
+  float4 xr[KI][2], nr[KI][2];
+  uint4 wq[KI][2];
+  int row[2];
+  __device__ __forceinline__ void request(const QkvFuse& f, int g, int slot, int n_q, int n_kv) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = slot * 16 + wave * 2 + i;  // row inside the kv head's (GROUP + 2) * 128
+      row[i] = r < GROUP * 128 ? g * GROUP * 128 + r
+             : r < GROUP * 128 + 128 ? n_q * 128 + g * 128 + (r - GROUP * 128)
+                                     : (n_q + n_kv) * 128 + g * 128 + (r - GROUP * 128 - 128);
+    }
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+      const int k = lane * 8 + it * 512;
+      xr[it][0] = *reinterpret_cast<const float4*>(f.x + k);
+      xr[it][1] = *reinterpret_cast<const float4*>(f.x + k + 4);
+      nr[it][0] = *reinterpret_cast<const float4*>(f.rms_w + k);
+      nr[it][1] = *reinterpret_cast<const float4*>(f.rms_w + k + 4);
+    }
+#pragma unroll
+    for (int it = 0; it < KI; ++it)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wq[it][i] = ld_stream16(f.W + (size_t)row[i] * f.K + lane * 8 + it * 512);
+  }
+  __device__ __forceinline__ void finish(const QkvFuse& f) {
+    const int lane = threadIdx.x & 63;
+    float x[KI][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+      const float4 v0 = xr[it][0], v1 = xr[it][1], w0 = nr[it][0], w1 = nr[it][1];
+      const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ss += xv[e] * xv[e]; x[it][e] = xv[e] * wv[e]; }
+    }
+    float acc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < KI; ++it)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = qa_dot8(wq[it][i], x[it], acc[i]);
+    const float rstd = 1.0f / sqrtf(wave_sum_fast(ss) / (float)f.K + f.eps);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float y = wave_sum_fast(acc[i]) * rstd + (f.bias ? f.bias[row[i]] : 0.f);
+      if (lane == 0) f.qkv_out[row[i]] = y;
+    }
+  }
+};
+
+// every wave has stored its rows: make them visible in the XCD's L2 and count this workgroup in
+__device__ __forceinline__ void xcd_arrive(unsigned* cnt) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a store is acknowledged when the L2 has it
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // RMW: executed in the L2
+}
+__device__ __forceinline__ void xcd_wait(unsigned* cnt, unsigned members, unsigned waiters) {
+  if (threadIdx.x == 0) {
+    int spins = 0;
+    while (__hip_atomic_fetch_add(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < members && ++spins < (1 << 16))
+      __builtin_amdgcn_s_sleep(1);
+    if (__hip_atomic_fetch_add(cnt + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == waiters - 1) {  // last one out
+      __hip_atomic_exchange(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_exchange(cnt + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's L1 lines of the qkv row (last layer's values)
+}
+
+template <int GROUP, typename KVT, int KI>
+__global__ __launch_bounds__(DA_WAVES * 64) void qkv_attn_kernel(DecodeAttnArgs a, QkvFuse f) {
+  static_assert(DA_WAVES == 8, "16 projection rows per workgroup = 8 waves x 2");
+  const int g = blockIdx.x & 7, slot = blockIdx.x >> 3;  // kv head = XCD, member of its 32 workgroups
+  unsigned* const cnt = f.sync + g * 64;
+  QkvRows<GROUP, KI> rows;
+  if (slot >= a.nsplit) {  // projection only
+    rows.request(f, g, slot, a.n_q, a.n_kv);
+    rows.finish(f);
+    xcd_arrive(cnt);
+    return;
+  }
+  decode_attn_body<GROUP, KVT>(a, g, 0, slot,
+      [&]() { rows.request(f, g, slot, a.n_q, a.n_kv); },
+      [&]() { rows.finish(f); xcd_arrive(cnt); xcd_wait(cnt, 32u, (unsigned)a.nsplit); });
 }
 
 
@@ -529,6 +665,24 @@ const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipS
   else if (group == 4) Q3A_DA(4);
   else return "decode_attn: GQA group must be 1, 2 or 4";
 #undef Q3A_DA
+  return nullptr;
+}
+
+const char* launch_qkv_attn(const DecodeAttnArgs& a, const QkvFuseArgs& fa, bool kv_f32, hipStream_t s) {
+  const int group = a.n_q / a.n_kv;
+  if (a.n_kv != 8 || group != 2) return "qkv_attn: 8 kv heads with 2 query heads each (one kv head per XCD)";
+  if (fa.K != 1024 && fa.K != 2048) return "qkv_attn: hidden size 1024 or 2048";
+  if (a.nsplit <= 0 || a.nsplit > 32 || a.nsplit * dattn_keys_per_split(kv_f32) < a.max_ctx) return "qkv_attn: 1..32 key splits covering max_ctx";
+  if (!fa.sync || !fa.rms_w || fa.qkv_out != a.qkv) return "qkv_attn: sync words, norm weight and the shared qkv row are required";
+  QkvFuse f{fa.x, fa.rms_w, fa.eps, fa.W, fa.bias, fa.K, fa.qkv_out, fa.sync};
+  const dim3 grid(256), block(DA_WAVES * 64);
+  if (fa.K == 1024) {
+    if (kv_f32) hipLaunchKernelGGL((qkv_attn_kernel<2, float, 2>), grid, block, 0, s, a, f);
+    else hipLaunchKernelGGL((qkv_attn_kernel<2, uint16_t, 2>), grid, block, 0, s, a, f);
+  } else {
+    if (kv_f32) hipLaunchKernelGGL((qkv_attn_kernel<2, float, 4>), grid, block, 0, s, a, f);
+    else hipLaunchKernelGGL((qkv_attn_kernel<2, uint16_t, 4>), grid, block, 0, s, a, f);
+  }
   return nullptr;
 }
 

@@ -215,6 +215,15 @@ struct DecodeAttnArgs {
 constexpr int DATTN_KEYS_PER_SPLIT_BF16 = 128, DATTN_KEYS_PER_SPLIT_F32 = 128;
 inline int dattn_keys_per_split(bool kv_f32) { return kv_f32 ? DATTN_KEYS_PER_SPLIT_F32 : DATTN_KEYS_PER_SPLIT_BF16; }
 const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
+// ONE sequence, 8 kv heads x 2 query heads: the qkv projection (RMSNorm fused, as the GEMV) and the attention splits in one
+// launch of 256 workgroups, handed over inside each XCD (k_dattn.hip qkv_attn_kernel).  a.qkv == f.qkv_out.
+struct QkvFuseArgs {
+  const float* x; const float* rms_w; float eps;  // hidden row [K], input-norm weight
+  const uint16_t* W; const float* bias; int K;    // [(n_q + 2 n_kv) * 128][K] bf16, bias or null
+  float* qkv_out;
+  unsigned* sync;                                  // >= 8 * 64 zeroed words, private to one stream
+};
+const char* launch_qkv_attn(const DecodeAttnArgs& a, const QkvFuseArgs& f, bool kv_f32, hipStream_t s);
 // one workgroup per (sequence, kv head), online softmax over 128-key tiles, final output written directly (a.out / a.out16)
 const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
 // out[S][n_q*128] = merged partials (needed as its own launch only on the GEMM decode path)
