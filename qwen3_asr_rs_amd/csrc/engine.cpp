@@ -533,7 +533,7 @@ struct q3a_engine {
     if (g_decode_parallel_groups < 0) { const char* e = getenv("Q3A_DECODE_PARALLEL"); g_decode_parallel_groups = e ? atoi(e) : 1; }
     gsize = (g_decode_group_size >= 1 && g_decode_group_size <= 32) ? g_decode_group_size : 32;
     const size_t ng = (size_t)n_groups(b);  // groups of <= gsize sequences of the batched decode step
-    if (!xcd_sync.p) { xcd_sync.ensure(8 * 64 * 4); HIPCHK(hipMemset(xcd_sync.p, 0, 8 * 64 * 4)); }  // (never inside a capture)
+    if (!xcd_sync.p) { xcd_sync.ensure(2 * 8 * 64 * 4); HIPCHK(hipMemset(xcd_sync.p, 0, 2 * 8 * 64 * 4)); }  // (never inside a capture)
     nn_x.ensure(ng * 32 * H * 2); nn_ss.ensure((size_t)ng * (H / 8) * 32 * 4);  // room for the finer (8-column) partial rows whichever shape the knob selects later
     x_dec.ensure((size_t)b * H * 4); next_tok.ensure((size_t)b * 4); forced_tok.ensure((size_t)b * 4);
     out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
@@ -731,6 +731,7 @@ struct q3a_engine {
         QkvFuseArgs fa{};
         fa.x = x; fa.rms_w = wf(l.in_ln); fa.eps = d.rms_eps; fa.W = wh(l.qkv_w); fa.bias = g.bias; fa.K = H;
         fa.qkv_out = qkv; fa.sync = xcd_sync.as<unsigned>();
+        fa.debug = opts.debug_taps ? xcd_sync.as<unsigned>() + 8 * 64 : nullptr;
         timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_qkv_attn(da, fa, kv_f32(), ks)); });
       } else {
         timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, ks)); });
@@ -846,6 +847,7 @@ struct q3a_engine {
     if (!opts.use_graph || prof) {
       for (int i = 0; i < n; ++i) enqueue_decode_step();
       HIPCHK(hipGetLastError());
+      if (xcd_sync.p) tap("xcd_sync", xcd_sync.p, 2 * 8 * 64 * 4);
       return;
     }
     std::string sig = make_graph_sig();
@@ -867,6 +869,7 @@ struct q3a_engine {
       graph_sig = sig;
     }
     for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(graph_exec, stream));
+    if (xcd_sync.p) tap("xcd_sync", xcd_sync.p, 2 * 8 * 64 * 4);  // (debug_taps only) counters + placement diagnostics of the fused launch
   }
 
   // steps 2-8 on the resident batch

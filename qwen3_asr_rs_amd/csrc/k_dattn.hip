@@ -275,6 +275,8 @@ struct QkvFuse {
   const uint16_t* W; const float* bias; int K;     // [(n_q + 2 n_kv) * 128][K]
   float* qkv_out;                                   // = DecodeAttnArgs::qkv
   unsigned* sync;                                   // [8][64] words: [g][0] arrivals, [g][32] departures
+  unsigned* debug;                                  // optional [8][64]: [g][slot] = XCC_ID the workgroup ran on, [g][32] = waits that
+                                                    // ran out, [g][33 + split] = arrivals seen when they did
 };
 
 __device__ __forceinline__ float qa_dot8(const uint4& w, const float (&x)[8], float s) {  // (k_gemv.hip dot8)
@@ -344,11 +346,13 @@ __device__ __forceinline__ void xcd_arrive(unsigned* cnt) {
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // RMW: executed in the L2
 }
-__device__ __forceinline__ void xcd_wait(unsigned* cnt, unsigned members, unsigned waiters) {
+__device__ __forceinline__ void xcd_wait(unsigned* cnt, unsigned members, unsigned waiters, unsigned* dbg, int slot) {
   if (threadIdx.x == 0) {
     int spins = 0;
-    while (__hip_atomic_fetch_add(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < members && ++spins < (1 << 16))
+    unsigned seen = 0;
+    while ((seen = __hip_atomic_fetch_add(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < members && ++spins < (1 << 16))
       __builtin_amdgcn_s_sleep(1);
+    if (dbg && seen < members) { atomicAdd(dbg + 32, 1u); dbg[33 + slot] = seen; }
     if (__hip_atomic_fetch_add(cnt + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == waiters - 1) {  // last one out
       __hip_atomic_exchange(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_exchange(cnt + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -363,6 +367,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void qkv_attn_kernel(DecodeAttnArgs 
   static_assert(DA_WAVES == 8, "16 projection rows per workgroup = 8 waves x 2");
   const int g = blockIdx.x & 7, slot = blockIdx.x >> 3;  // kv head = XCD, member of its 32 workgroups
   unsigned* const cnt = f.sync + g * 64;
+  unsigned* const dbg = f.debug ? f.debug + g * 64 : nullptr;
+  if (dbg && threadIdx.x == 0) dbg[slot] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) + 1u;  // HW_REG_XCC_ID[3:0] + 1
   QkvRows<GROUP, KI> rows;
   if (slot >= a.nsplit) {  // projection only
     rows.request(f, g, slot, a.n_q, a.n_kv);
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void qkv_attn_kernel(DecodeAttnArgs 
   }
   decode_attn_body<GROUP, KVT>(a, g, 0, slot,
       [&]() { rows.request(f, g, slot, a.n_q, a.n_kv); },
-      [&]() { rows.finish(f); xcd_arrive(cnt); xcd_wait(cnt, 32u, (unsigned)a.nsplit); });
+      [&]() { rows.finish(f); xcd_arrive(cnt); xcd_wait(cnt, 32u, (unsigned)a.nsplit, dbg, slot); });
 }
 
 
@@ -674,7 +680,7 @@ const char* launch_qkv_attn(const DecodeAttnArgs& a, const QkvFuseArgs& fa, bool
   if (fa.K != 1024 && fa.K != 2048) return "qkv_attn: hidden size 1024 or 2048";
   if (a.nsplit <= 0 || a.nsplit > 32 || a.nsplit * dattn_keys_per_split(kv_f32) < a.max_ctx) return "qkv_attn: 1..32 key splits covering max_ctx";
   if (!fa.sync || !fa.rms_w || fa.qkv_out != a.qkv) return "qkv_attn: sync words, norm weight and the shared qkv row are required";
-  QkvFuse f{fa.x, fa.rms_w, fa.eps, fa.W, fa.bias, fa.K, fa.qkv_out, fa.sync};
+  QkvFuse f{fa.x, fa.rms_w, fa.eps, fa.W, fa.bias, fa.K, fa.qkv_out, fa.sync, fa.debug};
   const dim3 grid(256), block(DA_WAVES * 64);
   if (fa.K == 1024) {
     if (kv_f32) hipLaunchKernelGGL((qkv_attn_kernel<2, float, 2>), grid, block, 0, s, a, f);

@@ -222,6 +222,7 @@ struct QkvFuseArgs {
   const uint16_t* W; const float* bias; int K;    // [(n_q + 2 n_kv) * 128][K] bf16, bias or null
   float* qkv_out;
   unsigned* sync;                                  // >= 8 * 64 zeroed words, private to one stream
+  unsigned* debug;                                 // optional 8 * 64 words of placement / time-out diagnostics (k_dattn.hip QkvFuse)
 };
 const char* launch_qkv_attn(const DecodeAttnArgs& a, const QkvFuseArgs& f, bool kv_f32, hipStream_t s);
 // one workgroup per (sequence, kv head), online softmax over 128-key tiles, final output written directly (a.out / a.out16)
