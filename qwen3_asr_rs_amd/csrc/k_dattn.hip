@@ -350,7 +350,10 @@ __device__ __forceinline__ void xcd_wait(unsigned* cnt, unsigned members, unsign
   if (threadIdx.x == 0) {
     int spins = 0;
     unsigned seen = 0;
-    while ((seen = __hip_atomic_fetch_add(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < members && ++spins < (1 << 16))
+    // The poll is an AGENT-scope load (sc1: served by the L2, past this CU's L1).  A workgroup-scope fetch_add(p, 0) is folded
+    // by the compiler into a workgroup-scope load (sc0), which keeps hitting the L1 line of the first poll: measured as
+    // waits that ran out at 29..31 of 32 arrivals in every second launch.
+    while ((seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < members && ++spins < (1 << 16))
       __builtin_amdgcn_s_sleep(1);
     if (dbg && seen < members) { atomicAdd(dbg + 32, 1u); dbg[33 + slot] = seen; }
     if (__hip_atomic_fetch_add(cnt + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == waiters - 1) {  // last one out
