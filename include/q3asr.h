@@ -234,7 +234,9 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *   "fuse_qkrope"        1 (default): batch-sized prefills run QK-norm + RoPE + the KV-cache append as the epilogue of the qkv
  *                        GEMM; 0: as the separate kernel (taken at the next prefill).
  *   "skinny_q"           1 (default): o / down projections of the batched decode step as 8-row x 16-sequence workgroups;
- *                        0: 16 rows x 32 sequences (taken at the next engine / batch set-up: it sizes a buffer). */
+ *                        0: 16 rows x 32 sequences (taken at the next engine / batch set-up: it sizes a buffer).
+ *   "fuse_qkv_attn"      0 (default) / 1: one-sequence decode runs the qkv projection and the attention key splits as ONE launch
+ *                        handed over inside each XCD (8 kv heads x 2 query heads only); taken at the next graph capture. */
 int32_t q3a_debug_set(const char* key, int32_t value);
 
 /* Kernel self-tests against naive device references (no model needed): returns max abs error. */
