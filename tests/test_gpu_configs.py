@@ -144,3 +144,29 @@ def test_1p7b_one_clip_default_mode_gemv_path():
     assert [int(t[0]) for t in T] == ids
     margin_report("1.7B B=1", ids, [l[0] for l in L], ref)
     eng.close()
+
+
+def test_one_launch_qkv_projection_and_attention_inside_each_xcd():
+    """One-sequence decode with the qkv projection and the attention key splits as ONE launch (k_dattn.hip qkv_attn_kernel,
+    off by default): the 32 workgroups of a kv head must all run on one XCD, no wait on the in-XCD arrival counter may run
+    out, and the greedy ids must equal the separate launches' (the projection rows are bit-identical)."""
+    from qwen3_asr_rs_amd import _lib
+    lib = _lib.load()
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
+    clip = synthetic.synthetic_clip(3, 30.0)
+    ids = {}
+    try:
+        for fuse in (1, 0):
+            assert lib.q3a_debug_set(b"fuse_qkv_attn", fuse) == 0
+            eng = HipEngine(d, 0, debug_taps=True, max_new_tokens=40)
+            ids[fuse] = eng.transcribe_batch([clip], None, max_new=40, fixed_new_tokens=40)[0]
+            if fuse:
+                w = np.frombuffer(eng.debug_read("xcd_sync").tobytes(), dtype=np.uint32).reshape(2, 8, 64)
+                for g in range(8):
+                    assert w[1, g, 32] == 0, f"kv head {g}: {w[1, g, 32]} waits ran out (arrivals seen {w[1, g, 33:37].tolist()})"
+                    assert len(set(w[1, g, :32].tolist())) == 1 and w[1, g, 0] > 0, f"kv head {g}: workgroups on XCCs {sorted(set(w[1, g, :32].tolist()))}"
+                    assert w[0, g, 0] == 0 and w[0, g, 32] == 0   # counters re-armed by the last split to leave
+            eng.close()
+        assert ids[1] == ids[0] and len(ids[0]) == 40
+    finally:
+        lib.q3a_debug_set(b"fuse_qkv_attn", 0)
