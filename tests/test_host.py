@@ -27,6 +27,21 @@ def test_exports_match_header(lib):
         assert hasattr(lib, name), f"libq3asr_hip.so does not export {name}"
 
 
+def test_debug_keys_are_documented_and_reject_unknown(lib):
+    """Every key q3a_debug_set accepts is described in include/q3asr.h (and vice versa); unknown keys are an error, no GPU needed."""
+    src = open(os.path.join(ROOT, "qwen3_asr_rs_amd", "csrc", "engine.cpp")).read()
+    body = src[src.index("int32_t q3a_debug_set("):]
+    body = body[:body.index("\n}\n")]
+    accepted = set(re.findall(r'strcmp\(key, "([a-z0-9_]+)"\)', body))
+    hdr = open(os.path.join(ROOT, "include", "q3asr.h")).read()
+    doc = hdr[:hdr.index("int32_t q3a_debug_set(")]
+    doc = doc[doc.rindex("/*"):]
+    documented = set(re.findall(r'^ \*   "([a-z0-9_]+)"', doc, flags=re.M))
+    assert accepted and accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
+    assert lib.q3a_debug_set(b"no_such_key", 1) != 0
+    assert b"no_such_key" in lib.q3a_last_error(None)
+
+
 def _arena(lib, model_dir):
     n = C.c_uint64()
     assert lib.q3a_arena_bytes(model_dir.encode(), C.byref(n)) == 0, lib.q3a_last_error(None)
