@@ -224,7 +224,9 @@ int32_t q3a_parse_asr_output(const char* raw, int32_t language_forced, char* lan
                              int32_t text_cap);
 int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
 
-/* A/B knobs for kernel experiments (process-wide; not part of the reference interface).  Keys:
+/* A/B knobs for kernel experiments (process-wide atomics, read from the environment once; not part of the reference
+ * interface).  The knobs that shape the decode step are latched per batch at the next prefill and are part of the captured
+ * graph's signature, so changing one on a live engine re-captures instead of replaying a stale graph.  Keys:
  *   "gemm256_min_tiles"  minimum number of 256x256 output tiles for which the bf16 GEMM dispatches to the 8-wave
  *                        counted-vmcnt kernel (k_gemm256.hip): 0 = whenever the shape allows, a huge value = never.
  *   "dattn_batched_min_wgs"  sequences x kv heads of a decode group from which the batched decode step uses the
@@ -236,7 +238,9 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *   "skinny_q"           1 (default): o / down projections of the batched decode step as 8-row x 16-sequence workgroups;
  *                        0: 16 rows x 32 sequences (taken at the next engine / batch set-up: it sizes a buffer).
  *   "fuse_qkv_attn"      0 (default) / 1: one-sequence decode runs the qkv projection and the attention key splits as ONE launch
- *                        handed over inside each XCD (8 kv heads x 2 query heads only); taken at the next graph capture. */
+ *                        handed over inside each XCD (8 kv heads x 2 query heads only); taken at the next prefill.
+ *   "eos_run_ahead"      decode steps the natural-EOS greedy loop keeps enqueued ahead of the device (default 2): the stop
+ *                        condition is evaluated on the device and read from pinned host memory without synchronising. */
 int32_t q3a_debug_set(const char* key, int32_t value);
 
 /* Kernel self-tests against naive device references (no model needed): returns max abs error. */

@@ -515,7 +515,8 @@ def text_mlp(weights, prefix, x):
 
 
 def text_decoder_forward(weights, cfg: TextDecoderConfig, hidden, cos, sin, kv: KvCache, mask,
-                         prefix: str = "thinker.model", taps: Optional[dict] = None, last_only: bool = False):
+                         prefix: str = "thinker.model", taps: Optional[dict] = None, last_only: bool = False,
+                         normed_out: Optional[list] = None):
     """text_decoder.rs:94-113 (+ layers.rs:442-463). `last_only=True` applies the final norm +
     lm_head to the last position only (same rows the caller keeps, inference.rs:156); it is an
     evaluation shortcut for big configs, the default follows the reference (all positions)."""
@@ -535,6 +536,7 @@ def text_decoder_forward(weights, cfg: TextDecoderConfig, hidden, cos, sin, kv: 
         hidden = hidden[:, -1:]
     if taps is not None and "dec_last_hidden" not in taps: taps["dec_last_hidden"] = hidden[0, -1]
     hidden = rms_norm(hidden, _w(weights, f"{prefix}.norm", "weight"), cfg.rms_norm_eps)
+    if normed_out is not None: normed_out.append(hidden[0, -1].clone())   # the row the lm_head multiplies (test tap)
     lm_head = _w(weights, prefix, "embed_tokens.weight") if cfg.tie_word_embeddings \
         else _w(weights, prefix.replace(".model", ".lm_head"), "weight")           # text_decoder.rs:71-79
     return hidden.matmul(lm_head.t())
@@ -570,6 +572,7 @@ class OracleResult:
     num_audio_tokens: int
     prompt_len: int
     taps: dict
+    step_hidden: List[torch.Tensor] = field(default_factory=list)  # want_hidden: final-normed last row per step (lm_head input)
 
 
 class AsrOracle:
@@ -589,7 +592,7 @@ class AsrOracle:
     def transcribe_ids(self, samples: np.ndarray, language_prefix_ids: Optional[Sequence[int]] = None,
                        max_new_tokens: int = 4096, fixed_new_tokens: int = 0,
                        forced_ids: Optional[Sequence[int]] = None, keep_logits: bool = True,
-                       last_only: bool = False, want_taps: bool = False) -> OracleResult:
+                       last_only: bool = False, want_taps: bool = False, want_hidden: bool = False) -> OracleResult:
         """fixed_new_tokens>0: ignore EOS and run exactly that many steps (throughput mode).
         forced_ids: teacher forcing -- feed these ids instead of the argmax (argmax still recorded)."""
         tc = self.cfg.text
@@ -608,7 +611,8 @@ class AsrOracle:
         cos, sin = compute_mrope_cos_sin(pos_ids, tc.head_dim, tc.rope_theta, tc.mrope_section, tc.mrope_interleaved)
         mask = create_causal_mask(P, 0)
         kv = KvCache(tc.num_hidden_layers)
-        logits = text_decoder_forward(self.weights, tc, hidden, cos, sin, kv, mask, taps=taps, last_only=last_only)
+        normed: Optional[list] = [] if want_hidden else None
+        logits = text_decoder_forward(self.weights, tc, hidden, cos, sin, kv, mask, taps=taps, last_only=last_only, normed_out=normed)
         next_logits = logits[:, -1]
         eos = (ENDOFTEXT_TOKEN_ID, IM_END_TOKEN_ID)
         gen: List[int] = []
@@ -630,12 +634,12 @@ class AsrOracle:
             nh = F.embedding(torch.tensor([feed], dtype=torch.int64), embed)[None]   # inference.rs:169-170
             c1, s1 = compute_mrope_cos_sin([[cur]] * 3, tc.head_dim, tc.rope_theta, tc.mrope_section, tc.mrope_interleaved)
             m1 = create_causal_mask(1, kv.seq_len())                                  # inference.rs:186-187
-            next_logits = text_decoder_forward(self.weights, tc, nh, c1, s1, kv, m1)[:, -1]
+            next_logits = text_decoder_forward(self.weights, tc, nh, c1, s1, kv, m1, normed_out=normed)[:, -1]
             cur += 1
         if forced_ids is not None:  # teacher forcing: also expose the logits after the last forced token
             if keep_logits: step_logits.append(next_logits[0].clone())
             all_ids.append(int(next_logits.argmax(-1)[0]))
-        return OracleResult(gen, all_ids, step_logits, T, P, taps if taps is not None else {})
+        return OracleResult(gen, all_ids, step_logits, T, P, taps if taps is not None else {}, normed or [])
 
 
 # ----------------------------------------------------------------------------------------

@@ -14,12 +14,15 @@
 // weights bf16; KV cache bf16 (fp32 in precise mode).
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -90,14 +93,26 @@ struct ProfEvent {
 namespace q3a {
 void set_thread_error(const std::string& msg) { g_last_error = msg; }  // used by host_abi.cpp
 }  // namespace q3a
-// A/B knobs of the batched decode step (environment at first use, q3a_debug_set afterwards): sequences per group (0 = 32)
-// and whether the groups run as parallel stream / graph branches (1) or one after the other on the engine's stream (0)
-static int g_decode_group_size = -1, g_decode_parallel_groups = -1;
-// A/B knob: QK-norm + RoPE + cache append as the qkv GEMM's epilogue in batch-sized prefills (Q3A_FUSE_QKROPE, default on)
-static int g_fuse_qkrope = -1;
-static int g_skinny_q = -1;
-// A/B knob: one-sequence decode runs the qkv projection and the attention splits as one launch (Q3A_FUSE_QKV_ATTN)
-static int g_fuse_qkv_attn = -1;
+// A/B knobs (kernels.h Knobs): read from the environment exactly once, atomics afterwards (q3a_debug_set writes them while
+// q3a_group_transcribe may have one host thread per GPU reading them)
+namespace q3a {
+Knobs& knobs() {
+  static Knobs k;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    auto env = [](const char* name, std::atomic<int>& dst) { if (const char* e = getenv(name)) dst.store(atoi(e)); };
+    env("Q3A_GEMM256_MIN_TILES", k.gemm256_min_tiles);
+    env("Q3A_DATTN_BATCHED_MIN_WGS", k.dattn_batched_min_wgs);
+    env("Q3A_DECODE_GROUP", k.decode_group_size);
+    env("Q3A_DECODE_PARALLEL", k.decode_parallel_groups);
+    env("Q3A_FUSE_QKROPE", k.fuse_qkrope);
+    env("Q3A_SKINNY_Q", k.skinny_q);
+    env("Q3A_FUSE_QKV_ATTN", k.fuse_qkv_attn);
+    env("Q3A_EOS_RUN_AHEAD", k.eos_run_ahead);
+  });
+  return k;
+}
+}  // namespace q3a
 
 struct q3a_engine {
   Dims d;
@@ -138,12 +153,18 @@ struct q3a_engine {
   DevBuf enc_ctx16, dec_ctx16;  // opts.valu_attention in the default mode: bf16 copy of the fp32 attention context
   DevBuf dec_q16;
   DevBuf xcd_sync;  // arrival / departure words of the fused qkv + attention launch (one kv head per XCD)
+  DevBuf n_done;    // device counter of sequences that have produced their EOS (argmax_finalize)
+  int* host_prog = nullptr;      // pinned host words written by argmax_finalize (FinalizeArgs::host_progress), polled without a sync
+  int* host_prog_dev = nullptr;  // the same words as the device sees them
   DevBuf zero_page;  // 256 B of zeros: padded filter taps of the bf16 implicit-GEMM convolutions read it
   int part_stride = 0, attn_nsplit = 0;
   size_t kv_layer_elems = 0;
 
   // ---- batched decode: sequence groups and their streams ----
   int gsize = 32;  // sequences per group of the batched decode step (<= 32: one skinny-GEMM weight sweep), fixed per batch
+  // knobs that shape the decode step, latched per batch in setup_prompts: producers outside the captured graph (prefill
+  // finalize, set_tokens) and the captured step must agree on them, and the graph signature names them
+  int k_parallel_groups = 1, k_skinny_q = 1, k_fuse_qkv_attn = 0, k_dattn_batched_min_wgs = 128;
   std::vector<hipStream_t> chain_streams;
   std::vector<hipEvent_t> join_ev;
   hipEvent_t fork_ev = nullptr;
@@ -234,6 +255,10 @@ struct q3a_engine {
     KCHK(skinny_init());
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+    HIPCHK(hipHostMalloc((void**)&host_prog, 64, hipHostMallocMapped));
+    memset(host_prog, 0, 64);
+    HIPCHK(hipHostGetDevicePointer((void**)&host_prog_dev, host_prog, 0));
+    n_done.ensure(64);
   }
 
   void init_tables() {
@@ -529,9 +554,13 @@ struct q3a_engine {
     kcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
     vcache.ensure(kv_layer_elems * d.dec_layers * kv_elem());
     rope_cur.ensure((size_t)b * 128 * 4);
-    if (g_decode_group_size < 0) { const char* e = getenv("Q3A_DECODE_GROUP"); g_decode_group_size = e ? atoi(e) : 0; }
-    if (g_decode_parallel_groups < 0) { const char* e = getenv("Q3A_DECODE_PARALLEL"); g_decode_parallel_groups = e ? atoi(e) : 1; }
-    gsize = (g_decode_group_size >= 1 && g_decode_group_size <= 32) ? g_decode_group_size : 32;
+    {
+      Knobs& kn = knobs();
+      const int gs = kn.decode_group_size.load();
+      gsize = (gs >= 1 && gs <= 32) ? gs : 32;
+      k_parallel_groups = kn.decode_parallel_groups.load(); k_skinny_q = kn.skinny_q.load();
+      k_fuse_qkv_attn = kn.fuse_qkv_attn.load(); k_dattn_batched_min_wgs = kn.dattn_batched_min_wgs.load();
+    }
     const size_t ng = (size_t)n_groups(b);  // groups of <= gsize sequences of the batched decode step
     if (!xcd_sync.p) { xcd_sync.ensure(2 * 8 * 64 * 4); HIPCHK(hipMemset(xcd_sync.p, 0, 2 * 8 * 64 * 4)); }  // (never inside a capture)
     nn_x.ensure(ng * 32 * H * 2); nn_ss.ensure((size_t)ng * (H / 8) * 32 * 4);  // room for the finer (8-column) partial rows whichever shape the knob selects later
@@ -547,6 +576,9 @@ struct q3a_engine {
     attn_po.ensure((size_t)b * d.n_q * attn_nsplit * 128 * 4);
     HIPCHK(hipMemsetAsync(step_count.p, 0, (size_t)b * 4, stream));
     HIPCHK(hipMemsetAsync(done.p, 0, (size_t)b, stream));
+    HIPCHK(hipMemsetAsync(n_done.p, 0, 64, stream));
+    __atomic_store_n(&host_prog[0], 0, __ATOMIC_RELAXED);  // (the stream is idle here: nothing on the device writes these)
+    __atomic_store_n(&host_prog[1], 0, __ATOMIC_RELAXED);
     HIPCHK(hipMemsetAsync(out_ids.p, 0, (size_t)b * max_new * 4, stream));
     HIPCHK(hipStreamSynchronize(stream));
   }
@@ -557,6 +589,7 @@ struct q3a_engine {
   // final norm + lm_head on x_dec -> logits (+ block argmax partials), then argmax/finalize
   void run_head(int advance) {
     const int S = B, H = d.hidden, V = d.vocab;
+    tap("head_in", x_dec.p, (size_t)S * H * 4);  // (debug taps) last-layer residual rows the final norm + lm_head read
     const double wbytes = 2.0 * V * H;
     int n_part = 0;
     if (S <= kGemvMaxSeq) {
@@ -584,7 +617,7 @@ struct q3a_engine {
     f.part_val = part_val.as<float>(); f.part_idx = part_idx.as<int>(); f.part_stride = part_stride; f.n_part = n_part;
     f.V = V; f.next_tok = next_tok.as<int>(); f.out_ids = out_ids.as<int>();
     f.out_stride = max_new; f.step_count = step_count.as<int>(); f.pos = d_pos.as<int>(); f.advance = advance;
-    f.done = done.as<uint8_t>(); f.embed = wh(L.embed); f.H = H; f.x_next = x_dec.as<float>(); f.eos0 = kEos0; f.eos1 = kEos1;
+    f.done = done.as<uint8_t>(); f.n_done = n_done.as<int>(); f.n_seq = S; f.host_progress = host_prog_dev; f.embed = wh(L.embed); f.H = H; f.x_next = x_dec.as<float>(); f.eos0 = kEos0; f.eos1 = kEos1;
     f.cos_t = rope_cos.as<float>(); f.sin_t = rope_sin.as<float>(); f.rope_cur = rope_cur.as<float>();
     f.nn = first_layer_norm_out();
     timed(Q3A_KC_ARGMAX, 0, [&] { KCHK(launch_argmax_finalize(f, S, stream)); });
@@ -607,8 +640,7 @@ struct q3a_engine {
     if (!valu_attn) { at.q16 = dec_q16.as<uint16_t>(); at.q_rs = QD; }  // the rope kernel leaves q as bf16 [rows][QD]
     const DevBuf& ctx_in = (valu_attn && !sp) ? dec_ctx16 : dec_ctx;  // what the o projection reads
     const bool qkv_bias = arena_flags & kFlagDecQkvBias, o_bias = arena_flags & kFlagDecOBias, mlp_bias = arena_flags & kFlagDecMlpBias;
-    if (g_fuse_qkrope < 0) { const char* e = getenv("Q3A_FUSE_QKROPE"); g_fuse_qkrope = e ? atoi(e) : 1; }
-    const bool fuse_rope = g_fuse_qkrope != 0 && !valu_attn && !precise() && d.head_dim == 128 && gemm256_eligible(total_P, QKV, H) && H % 64 == 0;
+    const bool fuse_rope = knobs().fuse_qkrope.load() != 0 && !valu_attn && !precise() && d.head_dim == 128 && gemm256_eligible(total_P, QKV, H) && H % 64 == 0;
     for (int li = 0; li < d.dec_layers; ++li) {
       const DecLayerOff& l = L.dec[li];
       KCHK(launch_rmsnorm(dec_x.as<float>(), wf(l.in_ln), dec_ln.as<float>(), total_P, H, d.rms_eps, stream, act16(dec_ln)));
@@ -666,9 +698,8 @@ struct q3a_engine {
   bool prenorm_path() const { return B > kGemvMaxSeq && !precise(); }
   // o / down projections of the batched decode step as 8-row x 16-sequence workgroups (k_skinny.hip QS; Q3A_SKINNY_Q=0: off)
   bool skinny_q() const {
-    if (g_skinny_q < 0) { const char* e = getenv("Q3A_SKINNY_Q"); g_skinny_q = e ? atoi(e) : 1; }
     auto whole = [](int K) { const int st = K / 32, per = (st + 7) / 8, unr = per <= 2 ? 2 : per <= 4 ? 4 : per <= 8 ? 8 : 12; return K % 256 == 0 && per % unr == 0; };
-    return g_skinny_q != 0 && !precise() && d.hidden % 64 == 0 && whole(d.q_dim()) && whole(d.inter);
+    return k_skinny_q != 0 && !precise() && d.hidden % 64 == 0 && whole(d.q_dim()) && whole(d.inter);
   }
   int nn_parts() const { return d.hidden / (skinny_q() ? 8 : 16); }  // one partial per 16- (8-) column block of a hidden-wide GEMM output
   // Batched decode (more than kGemvMaxSeq sequences) runs in groups of <= 32 sequences: the skinny MFMA GEMM holds 32
@@ -725,8 +756,7 @@ struct q3a_engine {
       GemvArgs g{};
       g.x = x; g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
       g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = qkv; g.ldo = QKV;
-      if (g_fuse_qkv_attn < 0) { const char* e = getenv("Q3A_FUSE_QKV_ATTN"); g_fuse_qkv_attn = e ? atoi(e) : 0; }
-      if (g_fuse_qkv_attn != 0 && S == 1 && d.n_kv == 8 && d.n_q == 16 && (H == 1024 || H == 2048) && attn_nsplit <= 32) {
+      if (k_fuse_qkv_attn != 0 && S == 1 && d.n_kv == 8 && d.n_q == 16 && (H == 1024 || H == 2048) && attn_nsplit <= 32) {
         // one kv head per XCD: projection rows and key splits of a head share that XCD's L2 (k_dattn.hip qkv_attn_kernel)
         QkvFuseArgs fa{};
         fa.x = x; fa.rms_w = wf(l.in_ln); fa.eps = d.rms_eps; fa.W = wh(l.qkv_w); fa.bias = g.bias; fa.K = H;
@@ -767,8 +797,7 @@ struct q3a_engine {
     else q.rms_w = wf(l.in_ln);
     q.bias = qkv_bias ? wf(l.qkv_b) : nullptr; q.mode = 0; q.out = qkv; q.ldo = QKV;
     timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { KCHK(launch_skinny(q, precise(), ks)); });
-    if (g_dattn_batched_min_wgs < 0) { const char* e = getenv("Q3A_DATTN_BATCHED_MIN_WGS"); g_dattn_batched_min_wgs = e ? atoi(e) : 128; }
-    if (S * d.n_kv >= g_dattn_batched_min_wgs) {
+    if (S * d.n_kv >= k_dattn_batched_min_wgs) {
       // the group alone fills the chip: one workgroup per (sequence, kv head) walks all keys and writes the context itself
       if (b16) { da.out16 = reinterpret_cast<uint16_t*>(s_ctx_g(grp)); da.out_frag = 1; } else da.out = s_ctx_g(grp);
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn_batched(da, S, kv_f32(), ks)); });
@@ -804,7 +833,7 @@ struct q3a_engine {
   // KV-streaming attention overlaps another group's weight-streaming GEMMs.  (Profiling runs keep everything on one stream.)
   void enqueue_decode_step() {
     const int ng = n_groups(B);
-    const bool chains = ng > 1 && !prof && g_decode_parallel_groups != 0;
+    const bool chains = ng > 1 && !prof && k_parallel_groups != 0;
     if (chains) {
       ensure_chain_streams(ng - 1);
       HIPCHK(hipEventRecord(fork_ev, stream));
@@ -835,9 +864,9 @@ struct q3a_engine {
   }
 
   std::string make_graph_sig() const {
-    char buf[256];
-    snprintf(buf, sizeof(buf), "%d.%d.%d/%d/%d/%p/%p/%p/%p/%p/%p/%p/%p", B, gsize, g_decode_parallel_groups, max_ctx, max_new, kcache.p, vcache.p, x_dec.p,
-             logits.p, s_qkv.p, out_ids.p, rope_cos.p, attn_po.p);
+    char buf[320];  // everything the captured step's launches depend on: geometry, latched knobs, buffer addresses
+    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d/%d/%d/%p/%p/%p/%p/%p/%p/%p/%p", B, gsize, k_parallel_groups, k_skinny_q, k_fuse_qkv_attn,
+             k_dattn_batched_min_wgs, max_ctx, max_new, kcache.p, vcache.p, x_dec.p, logits.p, s_qkv.p, out_ids.p, rope_cos.p, attn_po.p);
     return buf;
   }
 
@@ -900,17 +929,31 @@ struct q3a_engine {
       steps = fixed_new - 1;
       decode_steps(steps);
     } else {
-      const int chunk = 8;
-      std::vector<uint8_t> dn(B);
-      while (steps < max_new - 1) {
-        HIPCHK(hipMemcpyAsync(dn.data(), done.p, B, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        bool all = true;
-        for (int s = 0; s < B; ++s) all = all && dn[s];
-        if (all) break;
-        int n = std::min(chunk, max_new - 1 - steps);
-        decode_steps(n);
-        steps += n;
+      // Natural EOS (inference.rs:160-167).  The stop condition of the whole batch is evaluated on the device
+      // (argmax_finalize: n_done == B) and published to pinned host memory together with a progress counter; the host keeps
+      // `ahead` graph replays enqueued in front of the device and reads those two words -- no stream synchronisation and no
+      // D2H copy inside the loop, so the device never idles between steps.  Steps enqueued past a sequence's EOS only
+      // append ids that fetch_ids cuts off (each utterance ends at ITS first EOS); at most `ahead` whole-batch steps are
+      // wasted after the last sequence finishes.
+      const int ahead = std::max(1, knobs().eos_run_ahead.load());
+      const int limit = max_new - 1;
+      unsigned spins = 0;
+      while (steps < limit) {
+        if (__atomic_load_n(&host_prog[1], __ATOMIC_RELAXED)) break;
+        const int fin = __atomic_load_n(&host_prog[0], __ATOMIC_RELAXED);  // finalize launches completed (prefill = 1)
+        if (steps - std::max(fin - 1, 0) < ahead) {
+          decode_steps(1);
+          ++steps;
+          spins = 0;
+        } else if (++spins > 64) {
+          sched_yield();
+          if ((spins & 0xffff) == 0) {  // a device fault must end the wait: the progress words would never move again
+            const hipError_t q = hipStreamQuery(stream);
+            if (q != hipSuccess && q != hipErrorNotReady) HIPCHK(q);
+            if (q == hipSuccess && steps - std::max(__atomic_load_n(&host_prog[0], __ATOMIC_RELAXED) - 1, 0) >= ahead)
+              fail("greedy loop: the stream drained but the device-side progress counter did not advance");
+          }
+        }
       }
     }
     HIPCHK(hipEventRecord(ev[4], stream));
@@ -952,10 +995,11 @@ struct q3a_engine {
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
                       &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
                       &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po,
-                      &enc_ctx16, &dec_ctx16, &dec_q16, &xcd_sync, &zero_page, &rope_cur, &nn_x, &nn_ss};
+                      &enc_ctx16, &dec_ctx16, &dec_q16, &xcd_sync, &zero_page, &rope_cur, &nn_x, &nn_ss, &n_done};
     for (auto* b : bufs) b->release();
     for (auto& kv : taps) kv.second.release();
     if (own_arena && arena) (void)hipFree(arena);
+    if (host_prog) (void)hipHostFree(host_prog);
     for (auto& x : ev)
       if (x) (void)hipEventDestroy(x);
     if (stream) (void)hipStreamDestroy(stream);
@@ -1333,13 +1377,15 @@ int32_t q3a_debug_read(q3a_engine* e, const char* name, void* dst, uint64_t byte
 
 int32_t q3a_debug_set(const char* key, int32_t value) {
   if (!key) return 1;
-  if (strcmp(key, "gemm256_min_tiles") == 0) { g_gemm256_min_tiles = value; return 0; }
-  if (strcmp(key, "dattn_batched_min_wgs") == 0) { g_dattn_batched_min_wgs = value; return 0; }
-  if (strcmp(key, "decode_group_size") == 0) { g_decode_group_size = value; return 0; }
-  if (strcmp(key, "decode_parallel_groups") == 0) { g_decode_parallel_groups = value; return 0; }
-  if (strcmp(key, "fuse_qkrope") == 0) { g_fuse_qkrope = value; return 0; }
-  if (strcmp(key, "skinny_q") == 0) { g_skinny_q = value; return 0; }
-  if (strcmp(key, "fuse_qkv_attn") == 0) { g_fuse_qkv_attn = value; return 0; }
+  Knobs& kn = knobs();
+  if (strcmp(key, "gemm256_min_tiles") == 0) { kn.gemm256_min_tiles = value; return 0; }
+  if (strcmp(key, "dattn_batched_min_wgs") == 0) { kn.dattn_batched_min_wgs = value; return 0; }
+  if (strcmp(key, "decode_group_size") == 0) { kn.decode_group_size = value; return 0; }
+  if (strcmp(key, "decode_parallel_groups") == 0) { kn.decode_parallel_groups = value; return 0; }
+  if (strcmp(key, "fuse_qkrope") == 0) { kn.fuse_qkrope = value; return 0; }
+  if (strcmp(key, "skinny_q") == 0) { kn.skinny_q = value; return 0; }
+  if (strcmp(key, "fuse_qkv_attn") == 0) { kn.fuse_qkv_attn = value; return 0; }
+  if (strcmp(key, "eos_run_ahead") == 0) { kn.eos_run_ahead = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";
   return 1;
 }

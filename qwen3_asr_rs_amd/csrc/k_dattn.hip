@@ -695,9 +695,8 @@ const char* launch_qkv_attn(const DecodeAttnArgs& a, const QkvFuseArgs& fa, bool
   return nullptr;
 }
 
-// S * n_kv (= workgroups of the batched kernel) from which the engine's batched decode step uses it; below, the key-split
-// kernel + merge keep more CUs busy.  Environment Q3A_DATTN_BATCHED_MIN_WGS at first use, q3a_debug_set afterwards.
-int g_dattn_batched_min_wgs = -1;
+// (S * n_kv -- the workgroups of the batched kernel -- from which the engine's batched decode step uses it is the knob
+// dattn_batched_min_wgs of kernels.h; below it the key-split kernel + merge keep more CUs busy.)
 
 const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s) {
   if (S <= 0) return nullptr;

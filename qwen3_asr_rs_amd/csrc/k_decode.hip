@@ -174,7 +174,14 @@ __global__ __launch_bounds__(1024) void argmax_finalize_kernel(FinalizeArgs a) {
     const int np = a.pos[s] + a.advance;
     a.pos[s] = np;
     pos_s = np;
-    if (idx == a.eos0 || idx == a.eos1) a.done[s] = 1;
+    if ((idx == a.eos0 || idx == a.eos1) && !a.done[s]) {  // this sequence's first EOS (inference.rs:163-165)
+      a.done[s] = 1;
+      if (a.n_done) {
+        const int n = atomicAdd(a.n_done, 1) + 1;
+        if (n == a.n_seq && a.host_progress) __hip_atomic_store(a.host_progress + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    if (s == 0 && a.host_progress) __hip_atomic_store(a.host_progress, sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
   // RoPE row of the position the next decode step works at, at a fixed address: the attention kernels of that step

@@ -446,19 +446,14 @@ void launch256(const ALoader& A, const uint16_t* W, const uint16_t* zero, int M,
 }  // namespace
 
 // A/B knob: minimum number of 256 x 256 tiles for the dispatch to this kernel (0 = whenever the shape allows, huge = never);
-// environment Q3A_GEMM256_MIN_TILES at first use, q3a_debug_set("gemm256_min_tiles", v) afterwards
-int g_gemm256_min_tiles = -1;
+// environment Q3A_GEMM256_MIN_TILES at start-up, q3a_debug_set("gemm256_min_tiles", v) afterwards (kernels.h Knobs)
 bool gemm256_eligible(int M, int N, int K) {
-  if (g_gemm256_min_tiles < 0) {
-    const char* e = getenv("Q3A_GEMM256_MIN_TILES");
-    g_gemm256_min_tiles = e ? atoi(e) : 128;
-  }
   if (K % 32 != 0 || K < 2 * G_BK || N % 4 != 0) return false;
   // a few rows against a wide matrix (the decode-step lm_head at 5..64 sequences) is a weight stream, not MFMA work:
   // the 32-row tiles of the small kernel read it at 5.3 TB/s, a 256-row tile at 4.4 (58.8 vs 70 us for 32 x 151936)
   if (M < 128) return false;
   const long tiles = (long)((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-  return tiles >= g_gemm256_min_tiles;
+  return tiles >= knobs().gemm256_min_tiles.load(std::memory_order_relaxed);
 }
 
 // Rows [0, M1) that fill whole rounds of 256 tiles when the last round would hold at most `rem_max` tiles (0: no split).

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace q3a {
 
 // ---- GEMM (k_gemm.hip) -----------------------------------------------------------------------------
@@ -37,8 +39,19 @@ bool gemm256_eligible(int M, int N, int K);
 // launch_gemm16 without the dispatch to gemm256 (the 4-wave tiles of k_gemm16.hip): small problems and gemm256's split remainder
 const char* launch_gemm16_small(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
                                 bool glu, hipStream_t s);
-extern int g_gemm256_min_tiles;  // A/B knob, see k_gemm256.hip
-extern int g_dattn_batched_min_wgs;  // A/B knob, see k_dattn.hip: S * n_kv at which the decode step uses launch_decode_attn_batched
+// Process-wide A/B knobs (engine.cpp).  Initialised from the environment exactly once (std::call_once) and atomics
+// afterwards: q3a_group_transcribe drives one host thread per GPU through the code that reads them, q3a_debug_set writes them.
+struct Knobs {
+  std::atomic<int> gemm256_min_tiles{128};      // Q3A_GEMM256_MIN_TILES: 256 x 256 tiles from which gemm256 is used (k_gemm256.hip)
+  std::atomic<int> dattn_batched_min_wgs{128};  // Q3A_DATTN_BATCHED_MIN_WGS: S * n_kv from which launch_decode_attn_batched is used
+  std::atomic<int> decode_group_size{0};        // Q3A_DECODE_GROUP: sequences per group of the batched decode step (0 = 32)
+  std::atomic<int> decode_parallel_groups{1};   // Q3A_DECODE_PARALLEL: groups as parallel stream / graph branches
+  std::atomic<int> fuse_qkrope{1};              // Q3A_FUSE_QKROPE: QK-norm + RoPE + cache append as the qkv GEMM's epilogue
+  std::atomic<int> skinny_q{1};                 // Q3A_SKINNY_Q: quarter workgroups for the o / down projections
+  std::atomic<int> fuse_qkv_attn{0};            // Q3A_FUSE_QKV_ATTN: one-sequence decode qkv projection + attention in one launch
+  std::atomic<int> eos_run_ahead{2};            // Q3A_EOS_RUN_AHEAD: decode steps kept enqueued ahead of the device in natural-EOS mode
+};
+Knobs& knobs();
 const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
                            bool glu, hipStream_t s);
 const char* launch_conv3x3s2_gemm256(const uint16_t* X, const uint16_t* zero_page, int imgs, int H, int Wd, int C,
@@ -244,6 +257,11 @@ struct FinalizeArgs {
   int* pos;                // [S] += advance
   int advance;
   uint8_t* done;           // [S] sticky: set when the argmax is EOS
+  int* n_done;             // device counter of sequences whose done flag is set (nullable); n_seq = sequences in the batch
+  int n_seq;
+  int* host_progress;      // pinned host words the greedy loop's host side polls WITHOUT synchronising the stream (nullable):
+                           // [0] = finalize launches completed for sequence 0 (prefill counts as 1), [1] = 1 once every
+                           // sequence has produced its EOS (src/inference.rs:163-165 evaluated for the whole batch on the device)
   const uint16_t* embed; int H;
   float* x_next;           // [S][H] embedding of the chosen token
   int eos0, eos1;

@@ -10,7 +10,7 @@ import hashlib
 import json
 import os
 import struct
-from typing import Dict, Iterable, List, Optional, Tuple
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -55,7 +55,7 @@ CONFIG_TINY_UNTIED = {
 PRESETS = {"0.6b": CONFIG_0P6B, "1.7b": CONFIG_1P7B, "tiny": CONFIG_TINY, "tiny_untied": CONFIG_TINY_UNTIED}
 
 
-def tensor_specs(cfg: dict) -> List[Tuple[str, Tuple[int, ...], str, float]]:
+def tensor_specs(cfg: dict, embed_scale: float = 0.02) -> List[Tuple[str, Tuple[int, ...], str, float]]:
     """(key, shape, kind, scale) for every tensor of the reference key map (W2)."""
     a, t = cfg["audio_config"], cfg["text_config"]
     d, ffn, ch, mel = a["d_model"], a["encoder_ffn_dim"], a["downsample_hidden_size"], a["num_mel_bins"]
@@ -82,7 +82,7 @@ def tensor_specs(cfg: dict) -> List[Tuple[str, Tuple[int, ...], str, float]]:
     nq, nkv = t["num_attention_heads"], t["num_key_value_heads"]
     assert a["output_dim"] == h, "audio output_dim must equal decoder hidden_size"
     tm = "thinker.model"
-    s += [(f"{tm}.embed_tokens.weight", (t["vocab_size"], h), "w", 0.02)]
+    s += [(f"{tm}.embed_tokens.weight", (t["vocab_size"], h), "w", embed_scale)]
     for i in range(t["num_hidden_layers"]):
         p = f"{tm}.layers.{i}"
         s += [(f"{p}.input_layernorm.weight", (h,), "g", 0.1), (f"{p}.post_attention_layernorm.weight", (h,), "g", 0.1)]
@@ -133,13 +133,17 @@ def _write_safetensors(path: str, tensors: List[Tuple[str, torch.Tensor]], dtype
 
 
 def write_checkpoint(model_dir: str, preset: str = "tiny", seed: int = 0, shards: int = 1,
-                     cfg: Optional[dict] = None, eos_trap: bool = False, dtype: str = "BF16") -> str:
+                     cfg: Optional[dict] = None, eos_trap: bool = False, dtype: str = "BF16", embed_scale: float = 0.02) -> str:
     """Write config.json + model.safetensors (or `shards` shard files + index json, exercising
     the sharded path of src/weights.rs:29-58).  Idempotent: a finished directory is reused.
     eos_trap (untied lm_head only): column 0 of the lm_head is zeroed except +/-64 on the two EOS rows,
-    so every argmax is an EOS token -- exercises the stop condition of src/inference.rs:163-165."""
+    so every argmax is an EOS token -- exercises the stop condition of src/inference.rs:163-165.
+    embed_scale: std of the token-embedding rows.  With the default 0.02 the decoder state is dominated by the audio context
+    and greedy decoding repeats one token; a large value (with an untied lm_head) makes the state follow the token just fed,
+    so the greedy trajectory wanders through the vocabulary -- what plant_eos needs to place stops at chosen steps."""
     cfg = cfg or PRESETS[preset]
-    tag = hashlib.sha1(json.dumps([cfg, seed, shards, eos_trap] + ([dtype] if dtype != "BF16" else []), sort_keys=True).encode()).hexdigest()[:12]
+    tag = hashlib.sha1(json.dumps([cfg, seed, shards, eos_trap] + ([dtype] if dtype != "BF16" else [])
+                                  + ([embed_scale] if embed_scale != 0.02 else []), sort_keys=True).encode()).hexdigest()[:12]
     done = os.path.join(model_dir, f".complete.{tag}")
     if os.path.exists(done):
         return model_dir
@@ -147,7 +151,7 @@ def write_checkpoint(model_dir: str, preset: str = "tiny", seed: int = 0, shards
     with open(os.path.join(model_dir, "config.json"), "w") as f:
         json.dump({"thinker_config": cfg}, f, indent=1)
     gen = torch.Generator().manual_seed(seed)
-    specs = tensor_specs(cfg)
+    specs = tensor_specs(cfg, embed_scale)
     tensors = [(k, _gen_tensor(shape, kind, scale, gen)) for k, shape, kind, scale in specs]
     if eos_trap:
         assert not cfg["text_config"].get("tie_word_embeddings", True), "eos_trap needs an untied lm_head"
@@ -187,3 +191,92 @@ def synthetic_clip(index: int, seconds: float = 30.0, sample_rate: int = 16000) 
     x = x * (0.15 + 0.85 * env)
     x = 0.5 * x / np.max(np.abs(x))
     return x.astype(np.float32)
+
+
+# ---- checkpoints that emit EOS on purpose ----------------------------------------------------------------------------
+# Random-init weights never produce an EOS token, so the reference's stop condition (src/inference.rs:160-167: each
+# utterance breaks at ITS first EOS) would go untested and untimed.  The helpers below rewrite ONE row of the output
+# embedding -- the row of <|endoftext|> (151643), an EOS id that does not occur in the prompt, so nothing upstream of the
+# lm_head changes -- such that its logit wins at chosen decoder states and loses at all others.  Pure numpy: the states
+# come from whoever calls (the fp32 oracle in tests, the engine's own debug taps in bench.py).
+ENDOFTEXT_ID = 151643
+
+
+def _st_header(path: str):
+    with open(path, "rb") as f:
+        (n,) = struct.unpack("<Q", f.read(8))
+        return json.loads(f.read(n).decode("utf-8")), 8 + n
+
+
+def _locate_tensor(model_dir: str, key: str):
+    """(file, header entry, offset of the tensor's first byte in the file) -- single-file or sharded checkpoints."""
+    single = os.path.join(model_dir, "model.safetensors")
+    if os.path.exists(single):
+        path = single
+    else:
+        with open(os.path.join(model_dir, "model.safetensors.index.json")) as f:
+            path = os.path.join(model_dir, json.load(f)["weight_map"][key])
+    hdr, data0 = _st_header(path)
+    e = hdr[key]
+    return path, e, data0 + e["data_offsets"][0]
+
+
+def read_tensor(model_dir: str, key: str) -> np.ndarray:
+    """One tensor of a safetensors checkpoint as fp32 (BF16 / F16 / F32 storage)."""
+    path, e, off = _locate_tensor(model_dir, key)
+    tdt, idt, esz = _ST_DTYPES[e["dtype"]]
+    n = int(np.prod(e["shape"])) if e["shape"] else 1
+    with open(path, "rb") as f:
+        f.seek(off)
+        raw = np.frombuffer(f.read(n * esz), dtype=np.int16 if esz == 2 else np.int32)
+    return torch.from_numpy(raw.copy()).view(tdt).to(torch.float32).reshape(e["shape"]).numpy()
+
+
+def overwrite_row(model_dir: str, key: str, row: int, values: np.ndarray) -> np.ndarray:
+    """Overwrite one row of a 2-D tensor in place (values rounded to the tensor's storage type); returns the stored row
+    widened back to fp32."""
+    path, e, off = _locate_tensor(model_dir, key)
+    tdt, idt, esz = _ST_DTYPES[e["dtype"]]
+    rows, cols = e["shape"]
+    assert 0 <= row < rows and values.shape == (cols,)
+    stored = torch.from_numpy(np.asarray(values, dtype=np.float32)).to(tdt)
+    with open(path, "r+b") as f:
+        f.seek(off + row * cols * esz)
+        f.write(stored.contiguous().view(idt).numpy().tobytes())
+    return stored.to(torch.float32).numpy()
+
+
+def output_embedding_key(model_dir: str) -> str:
+    """Tensor the lm_head multiplies by (src/text_decoder.rs:71-79: tied -> the token embedding)."""
+    with open(os.path.join(model_dir, "config.json")) as f:
+        cfg = json.load(f)
+    t = cfg.get("thinker_config", cfg)["text_config"]
+    return "thinker.model.embed_tokens.weight" if t.get("tie_word_embeddings", True) else "thinker.lm_head.weight"
+
+
+def final_rms_norm(model_dir: str, x: np.ndarray) -> np.ndarray:
+    """The decoder's final RMSNorm (src/layers.rs:48-54 with thinker.model.norm.weight) on rows of `x` -- turns the
+    engine's "head_in" debug tap (last-layer residual rows) into the rows the lm_head multiplies."""
+    with open(os.path.join(model_dir, "config.json")) as f:
+        cfg = json.load(f)
+    eps = float(cfg.get("thinker_config", cfg)["text_config"].get("rms_norm_eps", 1e-6))
+    w = read_tensor(model_dir, "thinker.model.norm.weight").astype(np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    return (x / np.sqrt((x * x).mean(-1, keepdims=True) + eps) * w).astype(np.float32)
+
+
+def plant_eos(model_dir: str, states: np.ndarray, fire: Sequence[bool], hi: float = 12.0, lo: float = -12.0,
+              eos_id: int = ENDOFTEXT_ID) -> dict:
+    """Rewrite row `eos_id` of the output embedding so that its logit is ~`hi` at the lm_head input rows states[i] with
+    fire[i] and ~`lo` at all others (minimum-norm solution of the linear system; logits of random-init checkpoints stay
+    within a few units, so `hi` wins the argmax and `lo` never does).  Returns the achieved logits with the ROUNDED row."""
+    H = np.asarray(states, dtype=np.float64)
+    fire = np.asarray(fire, dtype=bool)
+    assert H.ndim == 2 and fire.shape == (H.shape[0],)
+    t = np.where(fire, hi, lo)
+    w, *_ = np.linalg.lstsq(H, t, rcond=None)
+    stored = overwrite_row(model_dir, output_embedding_key(model_dir), eos_id, w.astype(np.float32))
+    got = H @ stored.astype(np.float64)
+    return {"row_norm": float(np.linalg.norm(stored)), "logits": got,
+            "worst_fire": float(got[fire].min()) if fire.any() else None,
+            "worst_quiet": float(got[~fire].max()) if (~fire).any() else None}
