@@ -24,9 +24,9 @@ from qwen3_asr_rs_amd.engine import HipEngine
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = 0.12          # default-mode max |logit error| at 0.6B / 1.7B dims (|logit| <= ~3; measured ~1e-2)
+LOGIT_TOL = 0.05          # default-mode max |logit error| at 0.6B / 1.7B dims (|logit| <= ~3; measured 0.012-0.022)
 EMBED_TOL = 2e-2          # rel-L2 of the audio embeddings
-MAX_UNDER_MARGIN = 0.35   # at most this fraction of the compared steps may sit inside the rounding noise
+MAX_UNDER_MARGIN = 0.15   # at most this fraction of the compared steps may sit inside the rounding noise (measured <= 7 %)
 
 
 def rel_l2(got, ref):
@@ -35,7 +35,7 @@ def rel_l2(got, ref):
     return float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) + 1e-30))
 
 
-def margin_report(tag, eng_tokens, eng_logits, ref):
+def margin_report(tag, eng_tokens, eng_logits, ref, tol=None):
     """eng_tokens[s] / eng_logits[s]: the engine's greedy token and logits at step s (same history as `ref`, an
     OracleResult produced with forced_ids = the engine's tokens).  Returns (flips, under_margin, worst_err)."""
     n = len(eng_tokens)
@@ -54,19 +54,22 @@ def margin_report(tag, eng_tokens, eng_logits, ref):
             under += 1
         flips += 0 if same else 1
     print(f"[parity] {tag}: {n} steps, flips {flips}, under-margin {under} ({100.0 * under / n:.1f} %), worst |logit err| {worst:.4f}")
-    assert worst <= LOGIT_TOL, (tag, worst)
+    assert worst <= (LOGIT_TOL if tol is None else tol), (tag, worst)
     assert under <= MAX_UNDER_MARGIN * n, f"{tag}: {under}/{n} steps under the margin -- the exact-id bound is vacuous"
     return flips, under, worst
 
 
-def stepwise_logits(eng, prompts, forced, steps):
-    """Prefill + teacher-forced decode through the stage API: per-step logits [steps][B][V] and greedy tokens."""
+def stepwise_logits(eng, prompts, forced, steps, keep=None):
+    """Prefill + teacher-forced decode through the stage API: per-step logits and greedy tokens.  keep: the utterances
+    whose logits are kept ({b: [V] array} per step; None = the whole [B][V] array) -- 110 steps x 32 x 151 936 would not
+    fit in host memory."""
+    sel = (lambda a: a.copy()) if keep is None else (lambda a: {b: a[b].copy() for b in keep})
     logits, nxt = eng.prefill(prompts)
-    all_l, all_t = [logits.copy()], [nxt.copy()]
+    all_l, all_t = [sel(logits)], [nxt.copy()]
     for s in range(steps - 1):
         eng.set_next_tokens([f[s] for f in forced])
         lg, nx, _ = eng.decode_step()
-        all_l.append(lg.copy())
+        all_l.append(sel(lg))
         all_t.append(nx.copy())
     return all_l, all_t
 
@@ -90,6 +93,49 @@ def test_config1_0p6b_one_clip_100_tokens_free_running():
     eng.close()
 
 
+def test_config0_reference_clips_whole_path_0p6b_dims():
+    """BASELINE configs[0]'s workload -- the reference's own test_audio/sample{1,2,3}.wav (T = 104 / 54 / 73 audio tokens,
+    P = 119 / 69 / 88: at most 8 chunks, i.e. the no-mask case of src/audio_encoder.rs:181-183) -- through the WHOLE HIP path
+    (mel -> encoder -> prefill -> greedy decode) at the 0.6B dimensions against the oracle: one clip at a time as the
+    reference CLI runs them (GEMV decode path), precise mode (exact ids, fp32-level logits) and default mode (margin-aware
+    ids), then the three clips as one ragged batch (skinny MFMA decode path)."""
+    import os
+    from qwen3_asr_rs_amd.audio import load_audio
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test_audio")
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
+    clips = [load_audio(os.path.join(golden, f"sample{i}.wav"), 16000) for i in (1, 2, 3)]
+    assert [len(c) for c in clips] == [128000, 66560, 89600]
+    N = 16
+    orc = O.AsrOracle(d)
+    refs = [orc.transcribe_ids(c, fixed_new_tokens=N, last_only=True, want_taps=True) for c in clips]
+    assert [(r.num_audio_tokens, r.prompt_len) for r in refs] == [(104, 119), (54, 69), (73, 88)]
+
+    def on_history(clip, ids, ref):   # the oracle on the engine's own history (free-running ids may differ inside the noise)
+        return ref if list(ids[:N - 1]) == list(ref.all_step_ids[:N - 1]) else orc.transcribe_ids(clip, forced_ids=ids[:N - 1], last_only=True)
+
+    for precise in (True, False):
+        eng = HipEngine(d, 0, precise=precise, max_new_tokens=N)
+        for i, (clip, ref) in enumerate(zip(clips, refs)):
+            ids = eng.transcribe_batch([clip], None, max_new=N, fixed_new_tokens=N)[0]
+            eng.mel([clip])
+            emb = eng.encode()[0]
+            assert rel_l2(emb, ref.taps["audio_embeds"].numpy()) <= (1e-4 if precise else EMBED_TOL)
+            L, T = stepwise_logits(eng, [HipEngine.build_prompt(ref.num_audio_tokens)], [ids], N)
+            assert [int(t[0]) for t in T] == ids, "stage-API decode differs from the hipGraph-replayed decode"
+            # precise mode: fp32-level logits (<= 2e-4), so the ids are exact wherever the oracle's margin exceeds 4e-4
+            margin_report(f"config0 sample{i + 1}.wav 0.6B dims {'precise' if precise else 'default'} mode", ids, [l[0] for l in L],
+                          on_history(clip, ids, ref), tol=2e-4 if precise else None)
+        # the three clips as one ragged batch
+        ids = eng.transcribe_batch(clips, None, max_new=N, fixed_new_tokens=N)
+        eng.mel(clips); eng.encode()
+        L, T = stepwise_logits(eng, [HipEngine.build_prompt(r.num_audio_tokens) for r in refs], ids, N)
+        for b, (clip, ref) in enumerate(zip(clips, refs)):
+            assert [int(T[s][b]) for s in range(N)] == ids[b]
+            margin_report(f"config0 batch of 3, sample{b + 1}.wav, {'precise' if precise else 'default'} mode", ids[b],
+                          [L[s][b] for s in range(N)], on_history(clip, ids[b], ref), tol=2e-4 if precise else None)
+        eng.close()
+
+
 def _batch_config_check(tag, model_dir, B, check_utts, steps, free_tokens):
     clips = [synthetic.synthetic_clip(i, 30.0) for i in range(B)]
     eng = HipEngine(model_dir, 0, max_new_tokens=free_tokens)
@@ -97,7 +143,7 @@ def _batch_config_check(tag, model_dir, B, check_utts, steps, free_tokens):
     assert len(free) == B and all(len(x) == free_tokens for x in free)
     eng.mel(clips)
     emb = eng.encode()
-    L, T = stepwise_logits(eng, [HipEngine.build_prompt(390)] * B, free, steps)
+    L, T = stepwise_logits(eng, [HipEngine.build_prompt(390)] * B, free, steps, keep=check_utts)
     for s in range(steps):  # eager stage API == graph-replayed whole path, every utterance of the batch
         assert [int(x) for x in T[s]] == [free[b][s] for b in range(B)], f"{tag}: step {s} differs between stage API and whole path"
     orc = O.AsrOracle(model_dir)
@@ -119,16 +165,19 @@ def test_config2_0p6b_batch32_30s_default_mode():
     """BASELINE configs[2]: 0.6B dims, 32 x 30 s clips in ONE batch (encoder GEMMs at M = 12 480, conv2 implicit GEMM at
     M = 768 000, decode on the skinny MFMA path at 32 sequences).  Three utterances of the batch (first, middle, last)
     are compared with per-utterance oracle runs: audio embeddings, prefill logits, teacher-forced decode logits,
-    margin-aware exact ids; every utterance's eager decode must equal the graph-replayed one."""
+    margin-aware exact ids; every utterance's eager decode must equal the graph-replayed one.  110 free-running tokens:
+    the context grows from 405 to 515 keys, so the batched decode attention crosses the 128-key tile boundaries at 512
+    and the decode step is compared over more steps than bench.py times (100)."""
     d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
-    _batch_config_check("config2 0.6B B=32", d, 32, (0, 15, 31), steps=6, free_tokens=12)
+    _batch_config_check("config2 0.6B B=32", d, 32, (0, 31), steps=110, free_tokens=110)
 
 
 def test_config3_1p7b_batch16_30s_default_mode_sharded():
     """BASELINE configs[3]: 1.7B dims (expected dims), sharded safetensors, 16 x 30 s clips, DEFAULT
-    mode (K = 2048 / 6144 skinny GEMM and LDS-DMA GEMM shapes that the 0.6B checkpoints never reach)."""
+    mode (K = 2048 / 6144 skinny GEMM and LDS-DMA GEMM shapes that the 0.6B checkpoints never reach); 110 free-running
+    tokens as above (context 405 -> 515 keys)."""
     d = synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b", "1.7b", seed=0, shards=2)
-    _batch_config_check("config3 1.7B B=16", d, 16, (0, 15), steps=5, free_tokens=8)
+    _batch_config_check("config3 1.7B B=16", d, 16, (0, 15), steps=110, free_tokens=110)
 
 
 def test_1p7b_one_clip_default_mode_gemv_path():
