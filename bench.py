@@ -10,6 +10,12 @@ over one batch of synthetic 30 s clips.  Default workload = BASELINE.json config
 1 clip per GPU, 100 new tokens (EOS ignored: the weights are synthetic, so natural EOS never fires; 100 tokens / 30 s is
 the speech rate the survey fixes).  Rank 0 prints ONE JSON line.
 
+Launching.  N = 1: `python bench.py`.  N > 1: one process per GPU under torch.distributed.run (the driver's command above);
+a bare `python bench.py --gpus N` re-executes itself under torch.distributed.run on 127.0.0.1 with a free port, so the
+same command shape works at every N.  With N > 1 the line also carries `extra` legs: BASELINE configs[4]'s per-GPU
+workload (Qwen3-ASR-1.7B, 32 clips per GPU, weights shipped with ONE RCCL broadcast of the arena) and the native
+q3a_group_* path (one process, one host thread per GPU, RCCL called from C++).
+
 What is inside the clock
   value               PCM already resident in HBM when the clock starts (the task contract), generated ids fetched to the
                       host inside the clock (q3a_run_resident + q3a_fetch_ids).
@@ -25,6 +31,9 @@ roofline (dominant kernel = the one with the largest share of kernel time IN THE
                       HIP event pair on the engine's stream (no neighbours, no tracer).
   decode_stage        the whole decode stage from the HIP events that bracket it inside the timed steps:
                       algorithmic bytes per token / time per token.
+  natural_eos         the reference's own contract (src/inference.rs:160-167): fixed_new_tokens = 0 on a checkpoint whose
+                      <|endoftext|> row is planted so that THIS clip stops after exactly `new_tokens` tokens; the stop
+                      condition is evaluated on the device and read from pinned memory (no sync inside the loop).
   traffic             HBM bytes per launch of the dominant kernel from `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` child
                       passes of a shortened run of this workload (gfx950: FETCH_SIZE doubled for wide streaming reads,
                       MI355X_MICROARCH.md section HBM); `traffic_source` names where the number came from.
@@ -56,39 +65,40 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # ----------------------------------------------------------------------------------------------------------------
 # CPU baseline (the oracle = a port of the reference's tch-CPU op sequence), rank 0 at N=1 only
 # ----------------------------------------------------------------------------------------------------------------
-def cpu_baseline(model_dir: str, clip: np.ndarray, new_tokens: int, repeats: int = 3) -> dict:
+def cpu_baseline(model_dir: str, clip: np.ndarray, new_tokens: int, repeats: int = 5) -> dict:
     """The fp32 oracle (the reference's tch-CPU op sequence, inefficiencies included) timed on this box's host cores on
-    a bounded sample: one 30 s clip, front end + prefill + a few decode steps, extrapolated linearly to `new_tokens`
-    steps.  Median of `repeats` measurements per thread setting; the better thread setting is reported."""
+    a bounded sample: one 30 s clip, front end + prefill + 6 decode steps, extrapolated linearly to `new_tokens` steps
+    (t(k tokens) = t_front + k * t_step: two runs per measurement).  The thread setting is chosen by one probe run each
+    of {all cores, 16 threads} (libtorch's default is all cores; a GEMV-bound decode step is often faster on fewer), then
+    the median of `repeats` measurements with the better setting is reported."""
     from oracle import q3asr_oracle as O
     torch.set_grad_enabled(False)
     orc = O.AsrOracle(model_dir)
     secs = len(clip) / 16000.0
     all_cores = torch.get_num_threads()
-    best = None
-    # libtorch's default (all cores) is what the reference binary would use; a GEMV-bound decode step often runs
-    # faster on fewer threads, so the better of {all cores, 16 threads} is reported, with its core count.
+
+    def measure():
+        t0 = time.time(); orc.transcribe_ids(clip, fixed_new_tokens=2, keep_logits=False); t2 = time.time() - t0
+        t0 = time.time(); orc.transcribe_ids(clip, fixed_new_tokens=8, keep_logits=False); t8 = time.time() - t0
+        t_dec = max((t8 - t2) / 6.0, 0.0)
+        t_front = max(t2 - 2 * t_dec, 0.0)
+        return (t_front + new_tokens * t_dec, t_front, t_dec)
+
+    probe = {}
     for nt in sorted({all_cores, min(16, all_cores)}, reverse=True):
         torch.set_num_threads(nt)
         orc.transcribe_ids(clip, fixed_new_tokens=2, keep_logits=False)  # untimed: first-touch / thread-pool start
-        runs = []
-        for _ in range(repeats):
-            t0 = time.time(); orc.transcribe_ids(clip, fixed_new_tokens=2, keep_logits=False); t2 = time.time() - t0
-            t0 = time.time(); orc.transcribe_ids(clip, fixed_new_tokens=8, keep_logits=False); t8 = time.time() - t0
-            t_dec = max((t8 - t2) / 6.0, 0.0)
-            t_front = max(t2 - 2 * t_dec, 0.0)
-            runs.append((t_front + new_tokens * t_dec, t_front, t_dec))
-        runs.sort()
-        med = runs[len(runs) // 2]
-        if best is None or med[0] < best[0][0]:
-            best = (med, nt, [round(secs / r[0], 3) for r in runs])
+        probe[nt] = measure()
+    nt = min(probe, key=lambda k: probe[k][0])
+    torch.set_num_threads(nt)
+    runs = sorted([probe[nt]] + [measure() for _ in range(repeats - 1)])
     torch.set_num_threads(all_cores)
-    (total, t_front, t_dec), nt, rtfx_runs = best
+    total, t_front, t_dec = runs[len(runs) // 2]
     return {"value": round(secs / total, 3), "unit": "audio-seconds/sec", "cores": nt, "kind": "port",
-            "runs": rtfx_runs,
-            "sample": f"1 clip x {secs:.0f}s, median of {repeats} runs: mel+encoder+prefill {t_front:.2f}s, decode "
+            "runs": [round(secs / r[0], 3) for r in runs],
+            "sample": f"1 clip x {secs:.0f}s, median of {len(runs)} measurements: mel+encoder+prefill {t_front:.2f}s, decode "
                       f"{t_dec*1e3:.1f} ms/token measured over 6 tokens and extrapolated to {new_tokens} tokens; "
-                      f"best of {{{all_cores},16}} threads"}
+                      f"thread setting = better of {{{all_cores},16}} in a probe run each"}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -219,6 +229,152 @@ def inner_main(args):
     eng.close()
 
 
+def natural_eos_leg(preset, seconds, new_tokens, steps, warmup, precise, fixed_ms):
+    """The reference's stop contract timed beside the fixed-N number: one clip, fixed_new_tokens = 0, on a copy of the
+    checkpoint whose <|endoftext|> output row makes this clip emit EOS as token `new_tokens` + 1.  The row is planted
+    from the ENGINE's own decoder states (debug tap of the lm_head input over a teacher-free stage-API run; pure numpy,
+    no oracle), which the graph-replayed run reproduces bit for bit."""
+    from qwen3_asr_rs_amd import synthetic
+    from qwen3_asr_rs_amd.engine import HipEngine
+    eos_dir = f"/tmp/q3a_ckpt_{preset.replace('.', 'p')}_eosbench"
+    synthetic.write_checkpoint(eos_dir, preset, seed=0, shards=2 if preset == "1.7b" else 1)
+    key = synthetic.output_embedding_key(eos_dir)
+    H = synthetic._locate_tensor(eos_dir, key)[1]["shape"][1]
+    synthetic.overwrite_row(eos_dir, key, synthetic.ENDOFTEXT_ID, np.zeros(H, dtype=np.float32))  # un-plant a previous run
+    clip = synthetic.synthetic_clip(0, seconds)
+    cap = new_tokens + 8
+    eng = HipEngine(eos_dir, 0, precise=precise, debug_taps=True, max_new_tokens=cap)
+    eng.mel([clip]); eng.encode()
+    T = eng.num_audio_tokens(len(clip))
+    states = []
+    eng.prefill([HipEngine.build_prompt(T)], want_logits=False)
+    states.append(eng.debug_read("head_in").copy())
+    for _ in range(new_tokens):                 # states behind tokens 1 .. new_tokens (the last one must fire)
+        eng.decode_step(want_logits=False)
+        states.append(eng.debug_read("head_in").copy())
+    eng.close()
+    normed = synthetic.final_rms_norm(eos_dir, np.stack(states))
+    info = synthetic.plant_eos(eos_dir, normed, [i == new_tokens for i in range(len(states))])
+    eng = HipEngine(eos_dir, 0, precise=precise, max_new_tokens=cap)
+    eng.upload_pcm([clip])
+    for _ in range(warmup):
+        eng.run_resident(None, cap, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.run_resident(None, cap, 0)
+        ids = eng.fetch_ids(cap)
+    elapsed = time.perf_counter() - t0
+    stage = eng.timings()
+    eng.close()
+    ok = len(ids[0]) == new_tokens
+    return {"workload": f"Qwen3-ASR-{preset} bf16, 1 x {seconds:.0f}s clip, natural EOS after {new_tokens} tokens (max_new {cap})",
+            "value": round(seconds * steps / elapsed, 3), "unit": "audio-seconds/sec", "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "generated_tokens": len(ids[0]), "stopped_at_planned_token": ok,
+            "decode_steps_executed": int(stage["decode_steps"]), "decode_steps_needed": new_tokens,
+            "vs_fixed_n_ms": round(elapsed / steps * 1e3 - fixed_ms, 3),
+            "eos_row_norm": round(info["row_norm"], 2),
+            "what": "fixed_new_tokens = 0: stop condition evaluated on the device, polled from pinned host memory, "
+                    "eos_run_ahead = 2 graph replays enqueued ahead (no stream synchronisation inside the loop)"}
+
+
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def multi_gpu_command(n_gpus: int, argv, port: int = 0):
+    """The command a bare `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment) re-executes itself as:
+    one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def launch_check(args):
+    """`python bench.py --gpus N --launch-check`: the launch path of the N > 1 bench without a GPU (CPU tests): re-launch
+    under torch.distributed.run, rendezvous on 127.0.0.1, barrier, max over ranks, one JSON line from rank 0."""
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = multi_gpu_command(args.gpus, sys.argv[1:])
+        os.execv(cmd[0], cmd)
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        top = int(t.item())
+    else:
+        top = 1
+    if rank == 0:
+        print(json.dumps({"launch_check": {"world": world, "max_over_ranks": top, "master_addr": os.environ.get("MASTER_ADDR", "")}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def config4_leg(dist, dev, rank, world, local_rank, seconds, new_tokens, steps, warmup, precise):
+    """BASELINE configs[4] scaled to this N: Qwen3-ASR-1.7B, 32 clips per GPU, weights packed on rank 0 and shipped with one
+    RCCL broadcast of the arena; all ranks time the same window (barrier + max over ranks)."""
+    from qwen3_asr_rs_amd import synthetic
+    from qwen3_asr_rs_amd.distributed import broadcast_arena
+    B = 32
+    model_dir = "/tmp/q3a_ckpt_1p7b"
+    if rank == 0:
+        synthetic.write_checkpoint(model_dir, "1.7b", seed=0, shards=2)
+    dist.barrier()
+    t0 = time.perf_counter()
+    arena = broadcast_arena(model_dir, dev, src=0)
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t0
+    _, eng = make_engine("1.7b", model_dir, local_rank, precise, new_tokens, arena)
+    clips = [synthetic.synthetic_clip(rank * B + i, seconds) for i in range(B)]
+
+    def sync_all():
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+    elapsed = timed_region(eng, clips, steps, warmup, new_tokens, sync_all)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    stage = eng.timings()
+    eng.close()
+    del arena
+    return {"workload": f"Qwen3-ASR-1.7b bf16, {world} GPUs x batch={B} x {seconds:.0f}s clips ({world * B} clips), {new_tokens} new tokens (fixed)",
+            "value": round(world * B * seconds * steps / float(t.item()), 3), "unit": "audio-seconds/sec", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": round(float(t.item()) / steps * 1e3, 3),
+            "stage_ms_rank0": {k: round(float(v), 3) for k, v in stage.items() if k.endswith("_ms")},
+            "arena_broadcast_s": round(t_bcast, 3)}
+
+
+def native_group_leg(preset, ckpt_dir, world, B, seconds, new_tokens, steps, precise):
+    """The same workload through q3a_group_* (one process, one host thread per GPU, ncclBroadcast called from C++,
+    csrc/group.cpp), host PCM -> ids on the host: run on rank 0 while the other ranks wait at a barrier."""
+    from qwen3_asr_rs_amd import synthetic
+    from qwen3_asr_rs_amd.engine import HipGroup
+    model_dir = ckpt_dir or f"/tmp/q3a_ckpt_{preset.replace('.', 'p')}"
+    t0 = time.perf_counter()
+    grp = HipGroup(model_dir, n_gpus=world, precise=precise, max_new_tokens=max(new_tokens, 16))
+    t_create = time.perf_counter() - t0
+    clips = [synthetic.synthetic_clip(i, seconds) for i in range(world * B)]
+    grp.transcribe_batch(clips, None, max_new=new_tokens, fixed_new_tokens=new_tokens)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ids = grp.transcribe_batch(clips, None, max_new=new_tokens, fixed_new_tokens=new_tokens)
+    elapsed = time.perf_counter() - t0
+    out = {"workload": f"q3a_group_transcribe: Qwen3-ASR-{preset} bf16, {world} GPUs x {B} x {seconds:.0f}s clips, host PCM -> ids",
+           "value": round(world * B * seconds * steps / elapsed, 3), "unit": "audio-seconds/sec", "ms_per_step": round(elapsed / steps * 1e3, 3),
+           "ranks": grp.size, "used_rccl": grp.used_rccl, "group_create_s": round(t_create, 2),
+           "ids_ok": len(ids) == world * B and all(len(x) == new_tokens for x in ids)}
+    grp.close()
+    return out
+
+
 def extra_leg(preset, B, seconds, new_tokens, steps, warmup, precise):
     """One more single-GPU workload of BASELINE.json `configs` timed the same way (PCM resident, ids fetched)."""
     from qwen3_asr_rs_amd import synthetic
@@ -258,7 +414,12 @@ def main():
     ap.add_argument("--ckpt-dir", default=None)
     ap.add_argument("--trace-out", default=None, help="write the per-kernel table of the in-situ rocprofv3 kernel trace to this file")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only exercise the N > 1 launch path (self re-launch, rendezvous, barrier, max over ranks) on the gloo backend: no GPU needed")
     args = ap.parse_args()
+
+    if args.launch_check:
+        return launch_check(args)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
@@ -268,9 +429,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: same command shape as the N = 1 line -> one process per GPU
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} HIP device(s) visible")
+        cmd = multi_gpu_command(args.gpus, sys.argv[1:])
+        sys.stderr.write("[bench] re-launching as: " + " ".join(cmd) + "\n")
+        sys.stderr.flush()
+        os.execv(cmd[0], cmd)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -314,6 +481,20 @@ def main():
     P = int(stage["total_prompt_tokens"]) // B
     ab = algorithmic_bytes(dims, B, P, args.new_tokens)
     eng.close()
+    multi_extra = []
+    if dist is not None and not args.no_extra:
+        try:  # every rank takes part (collectives inside)
+            multi_extra.append(config4_leg(dist, dev, rank, world, local_rank, args.seconds, args.new_tokens, 2, 1, args.precise))
+        except Exception as ex:  # noqa: BLE001
+            multi_extra.append({"workload": "Qwen3-ASR-1.7b, 32 clips per GPU", "value": None, "error": str(ex)[:300]})
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:  # the native one-process group drives every GPU from this process; the other ranks idle at the barrier below
+            try:
+                multi_extra.append(native_group_leg(args.preset, args.ckpt_dir, world, B, args.seconds, args.new_tokens, args.steps, args.precise))
+            except Exception as ex:  # noqa: BLE001
+                multi_extra.append({"workload": "q3a_group_transcribe", "value": None, "error": str(ex)[:300]})
+        dist.barrier()
 
     if rank == 0:
         audio_seconds = world * B * args.seconds * args.steps
@@ -416,6 +597,12 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(model_dir, clips[0], args.new_tokens)
             except Exception as ex:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "error": str(ex)}
+        if world == 1 and not args.no_extra and B == 1:
+            try:
+                out["natural_eos"] = natural_eos_leg(args.preset, args.seconds, args.new_tokens, args.steps, args.warmup, args.precise,
+                                                     elapsed / args.steps * 1e3)
+            except Exception as ex:  # noqa: BLE001
+                out["natural_eos"] = {"value": None, "error": str(ex)[:300]}
         if world == 1 and not args.no_extra and args.preset == "0.6b" and B == 1:
             extra = []
             for preset, b in (("0.6b", 32), ("1.7b", 16)):
@@ -424,6 +611,8 @@ def main():
                 except Exception as ex:  # noqa: BLE001
                     extra.append({"workload": f"Qwen3-ASR-{preset} batch={b}", "value": None, "error": str(ex)[:300]})
             out["extra"] = extra
+        if multi_extra:
+            out["extra"] = multi_extra
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

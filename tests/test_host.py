@@ -229,3 +229,23 @@ def test_committed_bench_line_follows_the_contract():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and len(c["runs"]) >= 3
     ex = j["extra"]
     assert len(ex) == 2 and "batch=32" in ex[0]["workload"] and "1.7b" in ex[1]["workload"] and all(e["value"] > 0 for e in ex)
+
+
+def test_bench_n_gpu_launch_path_without_a_gpu():
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE re-launches itself under torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1); --launch-check runs exactly that path on the gloo backend: the processes fork,
+    meet, and rank 0 prints one JSON line carrying the max over ranks."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.multi_gpu_command(8, ["--gpus", "8", "--steps", "3"], port=29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True,
+                       text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)["launch_check"]
+    assert j == {"world": 2, "max_over_ranks": 2, "master_addr": "127.0.0.1"}
