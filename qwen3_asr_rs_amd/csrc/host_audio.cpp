@@ -129,8 +129,10 @@ void resample_rational(const std::vector<float>& in, int sr_in, int sr_out, std:
 //     Blackman-Harris over T points; sincs[F-1-n][p] = y[F*p + n] / (sum(y) / F);
 //   * the clip is preceded by 2*256 zeros; idx starts at -128 and advances by 1/ratio BEFORE each output; an output is the
 //     linear interpolation (fraction of idx*F) of the two nearest sub-filters applied to 256 input samples starting at
-//     floor(idx); the loop ends at idx >= n_in - 257.  Output n therefore sits at input time (n+1)/ratio and the last ~129
-//     input samples produce nothing (rubato would deliver them with the next chunk, which the reference never feeds).
+//     floor(idx); the loop ends at idx >= n_in - (sinc_len + 1) - ceil(1/ratio) (rubato's end_idx: the increment happens
+//     after the test, so without the ceil term the last window of a >= 2x decimation would start past the buffer).  Output n
+//     therefore sits at input time (n+1)/ratio and the last ~129 input samples produce nothing (rubato would deliver them
+//     with the next chunk, which the reference never feeds).
 void resample_rubato_sincfixedin(const std::vector<float>& in, int sr_in, int sr_out, std::vector<float>& out) {
   if (sr_in == sr_out) { out = in; return; }
   const double ratio = (double)sr_out / (double)sr_in;
@@ -156,7 +158,7 @@ void resample_rubato_sincfixedin(const std::vector<float>& in, int sr_in, int sr
   const int64_t n_in = (int64_t)in.size();
   std::vector<float> buf((size_t)(n_in + 2 * sinc_len), 0.f);
   std::copy(in.begin(), in.end(), buf.begin() + 2 * sinc_len);
-  const double t_ratio = 1.0 / ratio, end_idx = (double)(n_in - (sinc_len + 1));
+  const double t_ratio = 1.0 / ratio, end_idx = (double)(n_in - (sinc_len + 1)) - std::ceil(t_ratio);
   double idx = -(double)sinc_len / 2.0;
   out.clear();
   out.reserve((size_t)((double)n_in * ratio) + 8);

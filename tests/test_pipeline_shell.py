@@ -91,7 +91,7 @@ def test_reference_fallback_resampler_parameters(lib, monkeypatch):
     """src/audio.rs:220-245: rubato SincFixedIn {sinc_len 256, f_cutoff 0.95, Linear, oversampling 256, BlackmanHarris2}
     restated (csrc/host_audio.cpp resample_rubato_sincfixedin).  Not a bit-level pin (rubato cannot be built here); what is
     checked is the published algorithm's observable behaviour: output count (idx from -128 in steps of 1/ratio while
-    idx < n - 257), the sampling grid (output n at input time (n+1)/ratio - 1 + 1/256, i.e. 1.5 n + 0.504 at 24 -> 16 kHz),
+    idx < n - 257 - ceil(1/ratio)), the sampling grid (output n at input time (n+1)/ratio - 1 + 1/256, i.e. 1.5 n + 0.504 at 24 -> 16 kHz),
     unit pass-band gain, stop-band rejection, and the residual against this backend's default polyphase filter."""
     sr_in, sr_out = 24000, 16000
     n_in = 24000
@@ -99,10 +99,10 @@ def test_reference_fallback_resampler_parameters(lib, monkeypatch):
     x = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.25 * np.sin(2 * np.pi * 3000 * t + 0.3)).astype(np.float32)
     y = audio.resample(x, sr_in, sr_out, "rubato")
     idx, cnt = -128.0, 0
-    while idx < n_in - 257:
+    while idx < n_in - 257 - 2:   # rubato's end_idx subtracts ceil(1/ratio): the increment follows the test
         idx += 1.5
         cnt += 1
-    assert len(y) == cnt == 15914
+    assert len(y) == cnt == 15913
     to = (1.5 * np.arange(len(y)) + 1.5 - 1.0 + 1.0 / 256) / sr_in       # seconds on the input clock
     ref = 0.5 * np.sin(2 * np.pi * 440 * to) + 0.25 * np.sin(2 * np.pi * 3000 * to + 0.3)
     assert np.abs(y[300:-300] - ref[300:-300]).max() < 2e-3
@@ -114,7 +114,7 @@ def test_reference_fallback_resampler_parameters(lib, monkeypatch):
     w = wave.open(os.path.join(GOLDEN, "test_audio", "sample2.wav"))
     pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768
     a, b = audio.resample(pcm, 24000, 16000), audio.resample(pcm, 24000, 16000, "rubato")
-    assert len(a) == 66560 and len(b) == len(a) - 86
+    assert len(a) == 66560 and len(b) == len(a) - 87
     m = 65536
     fa, fb = np.fft.rfft(a[:m] * np.hanning(m)), np.fft.rfft(b[:m] * np.hanning(m))
     band = slice(int(100 * m / 16000), int(7000 * m / 16000))
@@ -122,6 +122,52 @@ def test_reference_fallback_resampler_parameters(lib, monkeypatch):
     # Q3A_RESAMPLER=rubato switches load_audio (and the CLI) to it
     monkeypatch.setenv("Q3A_RESAMPLER", "rubato")
     assert len(audio.load_audio(os.path.join(GOLDEN, "test_audio", "sample2.wav"), 16000)) == len(b)
+
+
+@pytest.mark.parametrize("sr_in", [48000, 44100, 32000, 22050, 8000])
+def test_reference_fallback_resampler_stays_inside_its_buffer(sr_in, tmp_path):
+    """Decimation by >= 2 (48 kHz / 44.1 kHz sources, the common case): the last interpolation window must end inside the
+    zero-padded buffer.  host_audio.cpp is compiled with AddressSanitizer into a tiny driver (no HIP involved) and run on
+    short and long inputs; the same inputs through the shipped library must give finite samples and rubato's output count."""
+    import math, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv = tmp_path / "drv.cpp"
+    drv.write_text('''
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "host.h"
+int main(int argc, char** argv) {
+  const int sr = atoi(argv[1]);
+  for (int n : {600, 1000, 4801, 48000}) {
+    std::vector<float> in((size_t)n), out;
+    for (int i = 0; i < n; ++i) in[i] = 0.5f * std::sin(0.01f * i);
+    q3a::resample_rubato_sincfixedin(in, sr, 16000, out);
+    for (float v : out) if (!std::isfinite(v)) return 2;
+    printf("%d %zu\\n", n, out.size());
+  }
+  return 0;
+}
+''')
+    exe = tmp_path / "drv"
+    csrc = os.path.join(root, "qwen3_asr_rs_amd", "csrc")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer", "-I", csrc, str(drv),
+                        os.path.join(csrc, "host_audio.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe), str(sr_in)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr[-3000:])
+    t_ratio = sr_in / 16000.0
+    for line in r.stdout.splitlines():
+        n, got = map(int, line.split())
+        idx, cnt = -128.0, 0
+        while idx < n - 257 - math.ceil(t_ratio):
+            idx += t_ratio
+            cnt += 1
+        assert got == cnt, (sr_in, n, got, cnt)
+        x = (0.5 * np.sin(0.01 * np.arange(n))).astype(np.float32)
+        y = audio.resample(x, sr_in, 16000, "rubato")
+        assert len(y) == cnt and np.isfinite(y).all()
 
 
 @pytest.fixture(scope="module")
