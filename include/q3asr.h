@@ -214,10 +214,12 @@ void q3a_tokenizer_destroy(q3a_tokenizer* t);
 /* decode(ids, skip_special_tokens) -> UTF-8 (tokenizer.rs:42-49). *len = bytes needed (excluding NUL). */
 int32_t q3a_tokenizer_decode(const q3a_tokenizer* t, const int32_t* ids, int32_t n, int32_t skip_special, char* out,
                              int32_t cap, int32_t* len);
-/* encode(text, add_special_tokens = false) (tokenizer.rs:33-39): added tokens cut out first, then the Qwen2 pre-tokenisation
- * pattern over Unicode code points and byte-level BPE.  UTF-8 in, no NFC normalisation (pass NFC text; ASCII prompts such
- * as "language English", the reference's only use, inference.rs:246-251, are). */
+/* encode(text, add_special_tokens = false) (tokenizer.rs:33-39): added tokens cut out first, then the normaliser
+ * tokenizer.json names (NFC for Qwen), the Qwen2 pre-tokenisation pattern over Unicode code points and byte-level BPE.  UTF-8 in. */
 int32_t q3a_tokenizer_encode(const q3a_tokenizer* t, const char* text, int32_t* ids, int32_t cap, int32_t* n);
+/* The normaliser step on its own: Unicode NFC (UAX #15; decomposition / composition data of Unicode 13.0 -- later additions
+ * pass through unchanged).  *len = bytes needed (excluding NUL). */
+int32_t q3a_normalize_nfc(const char* utf8, char* out, int32_t cap, int32_t* len);
 
 /* parse_asr_output (src/inference.rs:276-305); capitalize_first (inference.rs:307-313). */
 int32_t q3a_parse_asr_output(const char* raw, int32_t language_forced, char* language, int32_t language_cap, char* text,

@@ -17,7 +17,7 @@ SYMBOLS = [
     "q3a_upload_pcm", "q3a_run_resident", "q3a_fetch_ids", "q3a_transcribe_batch", "q3a_stage_timings",
     "q3a_profile_decode_step", "q3a_profile_weight_stream", "q3a_debug_read", "q3a_debug_set", "q3a_selftest_gemm", "q3a_selftest_gemm16",
     "q3a_load_audio", "q3a_resample", "q3a_resample_rubato", "q3a_free", "q3a_tokenizer_create", "q3a_tokenizer_destroy",
-    "q3a_tokenizer_decode", "q3a_tokenizer_encode", "q3a_parse_asr_output", "q3a_capitalize_first",
+    "q3a_tokenizer_decode", "q3a_tokenizer_encode", "q3a_normalize_nfc", "q3a_parse_asr_output", "q3a_capitalize_first",
     "q3a_group_create", "q3a_group_destroy", "q3a_group_size", "q3a_group_used_rccl", "q3a_group_last_error",
     "q3a_group_engine", "q3a_group_partition", "q3a_group_transcribe",
 ]
@@ -102,6 +102,7 @@ def load() -> C.CDLL:
         "q3a_tokenizer_encode": (i32, [P, C.c_char_p, i32p, i32, i32p]),
         "q3a_parse_asr_output": (i32, [C.c_char_p, i32, C.c_char_p, i32, C.c_char_p, i32]),
         "q3a_capitalize_first": (i32, [C.c_char_p, C.c_char_p, i32]),
+        "q3a_normalize_nfc": (i32, [C.c_char_p, C.c_char_p, i32, i32p]),
         "q3a_group_create": (i32, [C.c_char_p, i32, i32p, C.POINTER(Opts), C.POINTER(P)]),
         "q3a_group_destroy": (None, [P]),
         "q3a_group_size": (i32, [P]),

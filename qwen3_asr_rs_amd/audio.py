@@ -99,3 +99,14 @@ def capitalize_first(s: str) -> str:
     out = C.create_string_buffer(len(s.encode("utf-8")) + 8)
     lib.q3a_capitalize_first(s.encode("utf-8"), out, len(out))
     return out.value.decode("utf-8")
+
+
+def normalize_nfc(s: str) -> str:
+    """The normaliser step of the tokenizer (Unicode NFC, csrc/host_text.cpp normalize_nfc)."""
+    lib = _lib.load()
+    raw = s.encode("utf-8")
+    n = C.c_int32()
+    out = C.create_string_buffer(3 * len(raw) + 16)
+    if lib.q3a_normalize_nfc(raw, out, len(out), C.byref(n)) != 0:
+        raise RuntimeError(_err())
+    return out.raw[:n.value].decode("utf-8")

@@ -22,9 +22,10 @@ class BpeTokenizer {
   explicit BpeTokenizer(const std::string& tokenizer_json_path);      // tokenizer.rs:11-30
   std::string decode(const std::vector<int64_t>& ids, bool skip_special = true) const;  // tokenizer.rs:42-49
   // encode(text, add_special_tokens = false), tokenizer.rs:33-39: added tokens are cut out first (longest match), the rest goes
-  // through the Qwen2 pre-tokenisation pattern over Unicode code points (\p{L}, \p{N}, \s from generated tables) and
-  // byte-level BPE.  No normaliser (the Qwen tokenizer.json asks for NFC): the caller passes NFC text.
+  // through the normaliser (NFC when tokenizer.json asks for it, as Qwen's does), the Qwen2 pre-tokenisation pattern over
+  // Unicode code points (\p{L}, \p{N}, \s from generated tables) and byte-level BPE.
   std::vector<int64_t> encode(const std::string& text) const;
+  bool normalizes_nfc() const { return nfc_; }
   size_t vocab_size() const { return id_to_token_.size(); }
 
  private:
@@ -34,7 +35,11 @@ class BpeTokenizer {
   std::vector<bool> is_special_, is_added_;
   std::vector<int> byte_of_cp_;                          // mapped code point -> byte (-1: none)
   std::vector<std::string> cp_of_byte_;                  // byte -> UTF-8 of its mapped code point
+  std::vector<std::vector<int64_t>> added_by_first_;     // added tokens by first byte, longest first
+  bool nfc_ = false;                                     // tokenizer.json "normalizer" is (or contains) NFC
 };
+// Unicode NFC of a UTF-8 string (generated tables: unicode_tables.h)
+std::string normalize_nfc(const std::string& utf8);
 
 // ---- output parsing (host_text.cpp; reference: src/inference.rs:276-313) ----
 void parse_asr_output(const std::string& raw, bool language_forced, std::string& language, std::string& text);

@@ -109,6 +109,13 @@ int32_t q3a_parse_asr_output(const char* raw, int32_t language_forced, char* lan
   put_str(t, text, text_cap);
   HOST_CATCH
 }
+int32_t q3a_normalize_nfc(const char* utf8, char* out, int32_t cap, int32_t* len) {
+  HOST_TRY
+  const std::string r = normalize_nfc(utf8 ? utf8 : "");
+  if (len) *len = (int32_t)r.size();
+  put_str(r, out, cap);
+  HOST_CATCH
+}
 int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap) {
   HOST_TRY
   put_str(capitalize_first(s ? s : ""), out, cap);

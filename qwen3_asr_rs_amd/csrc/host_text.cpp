@@ -102,7 +102,90 @@ size_t match_piece(const std::vector<uint32_t>& t, size_t i) {
   return i + 1;
 }
 
+// ---- NFC (Unicode Standard Annex #15) over code points; tables in unicode_tables.h ----
+constexpr uint32_t SBase = 0xAC00, LBase = 0x1100, VBase = 0x1161, TBase = 0x11A7, LCount = 19, VCount = 21, TCount = 28,
+                   NCount = VCount * TCount, SCount = LCount * NCount;
+uint8_t ccc_of(uint32_t cp) {
+  int lo = 0, hi = kNfcCcc_n - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cp < kNfcCcc[mid].lo) hi = mid - 1;
+    else if (cp > kNfcCcc[mid].hi) lo = mid + 1;
+    else return kNfcCcc[mid].ccc;
+  }
+  return 0;
+}
+void decompose_into(uint32_t cp, std::vector<uint32_t>& out) {  // full canonical decomposition (recursive)
+  if (cp >= SBase && cp < SBase + SCount) {  // Hangul syllable -> L V (T)
+    const uint32_t si = cp - SBase;
+    out.push_back(LBase + si / NCount);
+    out.push_back(VBase + (si % NCount) / TCount);
+    if (si % TCount) out.push_back(TBase + si % TCount);
+    return;
+  }
+  int lo = 0, hi = kNfcDecomp_n - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cp < kNfcDecomp[mid].cp) hi = mid - 1;
+    else if (cp > kNfcDecomp[mid].cp) lo = mid + 1;
+    else {
+      decompose_into(kNfcDecomp[mid].a, out);
+      if (kNfcDecomp[mid].b) decompose_into(kNfcDecomp[mid].b, out);
+      return;
+    }
+  }
+  out.push_back(cp);
+}
+uint32_t compose_pair(uint32_t a, uint32_t b) {  // 0: no primary composite
+  if (a >= LBase && a < LBase + LCount && b >= VBase && b < VBase + VCount) return SBase + ((a - LBase) * VCount + (b - VBase)) * TCount;
+  if (a >= SBase && a < SBase + SCount && (a - SBase) % TCount == 0 && b > TBase && b < TBase + TCount) return a + (b - TBase);
+  int lo = 0, hi = kNfcComp_n - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const CpComp& e = kNfcComp[mid];
+    if (a < e.a || (a == e.a && b < e.b)) hi = mid - 1;
+    else if (a > e.a || (a == e.a && b > e.b)) lo = mid + 1;
+    else return e.cp;
+  }
+  return 0;
+}
+
 }  // namespace
+
+// NFC of a UTF-8 string (the normaliser of Qwen's tokenizer.json).  Text below U+0300 holds no combining mark and no
+// decomposable-but-uncomposed sequence, so it is returned as is (the reference's only use, "language English", is ASCII).
+std::string normalize_nfc(const std::string& in) {
+  std::vector<uint32_t> cps;
+  bool low = true;
+  for (size_t i = 0; i < in.size();) { const uint32_t c = next_cp(in, i); cps.push_back(c); low = low && c < 0x300; }
+  if (low) return in;
+  std::vector<uint32_t> d;
+  for (uint32_t c : cps) decompose_into(c, d);
+  // canonical ordering: stable sort of every run of non-starters by combining class
+  for (size_t i = 0; i < d.size();) {
+    if (ccc_of(d[i]) == 0) { ++i; continue; }
+    size_t j = i;
+    while (j < d.size() && ccc_of(d[j]) != 0) ++j;
+    std::stable_sort(d.begin() + (long)i, d.begin() + (long)j, [](uint32_t x, uint32_t y) { return ccc_of(x) < ccc_of(y); });
+    i = j;
+  }
+  // canonical composition
+  std::vector<uint32_t> o;
+  long starter = -1;      // index in o of the last starter
+  int last_ccc = -1;      // combining class of the last character kept after that starter (-1: none yet)
+  for (uint32_t c : d) {
+    const int k = ccc_of(c);
+    if (starter >= 0 && (last_ccc < k || last_ccc == -1)) {  // not blocked (adjacent, or every class in between is lower)
+      const uint32_t comp = (last_ccc == -1 || k != 0) ? compose_pair(o[(size_t)starter], c) : 0;
+      if (comp) { o[(size_t)starter] = comp; continue; }
+    }
+    if (k == 0) { starter = (long)o.size(); last_ccc = -1; } else last_ccc = k;
+    o.push_back(c);
+  }
+  std::string out;
+  for (uint32_t c : o) out += utf8_of(c);
+  return out;
+}
 
 BpeTokenizer::BpeTokenizer(const std::string& path) {
   Json root = parse_json(read_file(path));
@@ -134,6 +217,20 @@ BpeTokenizer::BpeTokenizer(const std::string& path) {
       if (m.kind == Json::Str) merge_rank_[m.str] = rank++;                                   // "left right"
       else if (m.kind == Json::Arr && m.arr.size() == 2) merge_rank_[m.arr[0].str + " " + m.arr[1].str] = rank++;
     }
+  }
+  // added tokens bucketed by their first byte, longest first: the cut in encode() looks at one short bucket per position
+  added_by_first_.assign(256, {});
+  for (size_t id = 0; id < id_to_token_.size(); ++id)
+    if (is_added_[id] && !id_to_token_[id].empty()) added_by_first_[(unsigned char)id_to_token_[id][0]].push_back((int64_t)id);
+  for (auto& b : added_by_first_)
+    std::stable_sort(b.begin(), b.end(), [&](int64_t x, int64_t y) { return id_to_token_[(size_t)x].size() > id_to_token_[(size_t)y].size(); });
+  // "normalizer": {"type": "NFC"} (Qwen) or a Sequence that contains one
+  if (const Json* nz = root.find("normalizer")) {
+    auto is_nfc = [](const Json& j) { const Json* t = j.kind == Json::Obj ? j.find("type") : nullptr; return t && t->kind == Json::Str && t->str == "NFC"; };
+    nfc_ = is_nfc(*nz);
+    if (nz->kind == Json::Obj)
+      if (const Json* seq = nz->find("normalizers"))
+        for (auto& e : seq->arr) nfc_ = nfc_ || is_nfc(e);
   }
   // GPT-2 byte <-> unicode table: printable bytes map to themselves, the rest to U+0100 + n
   byte_of_cp_.assign(512, -1);
@@ -180,10 +277,11 @@ std::string BpeTokenizer::decode(const std::vector<int64_t>& ids, bool skip_spec
 
 std::vector<int64_t> BpeTokenizer::encode(const std::string& text) const {
   // tokenizers' AddedVocabulary first cuts the added tokens (special or not) out of the text, longest match at the
-  // leftmost position; the stretches in between go through the pre-tokeniser + byte-level BPE.  (No normaliser: the Qwen
-  // tokenizer.json asks for NFC, so the caller must pass NFC text -- ASCII prompts such as "language English" are.)
+  // leftmost position; the stretches in between go through the normaliser (NFC when tokenizer.json asks for it), the
+  // pre-tokeniser and byte-level BPE.
   std::vector<int64_t> ids;
-  auto encode_plain = [&](const std::string& seg) {
+  auto encode_plain = [&](const std::string& raw_seg) {
+    const std::string seg = nfc_ ? normalize_nfc(raw_seg) : raw_seg;
     std::vector<uint32_t> cps;
     std::vector<size_t> off;  // byte offset of every code point (+ end)
     for (size_t i = 0; i < seg.size();) { off.push_back(i); cps.push_back(next_cp(seg, i)); }
@@ -215,12 +313,9 @@ std::vector<int64_t> BpeTokenizer::encode(const std::string& text) const {
   while (i < text.size()) {
     size_t best_len = 0;
     int64_t best_id = -1;
-    if (text[i] == '<' || true) {
-      for (size_t id = 0; id < id_to_token_.size(); ++id) {
-        if (!is_added_[id]) continue;
-        const std::string& tk = id_to_token_[id];
-        if (tk.size() > best_len && !tk.empty() && text.compare(i, tk.size(), tk) == 0) { best_len = tk.size(); best_id = (int64_t)id; }
-      }
+    for (int64_t id : added_by_first_[(unsigned char)text[i]]) {  // longest first: the first hit is the longest match
+      const std::string& tk = id_to_token_[(size_t)id];
+      if (text.compare(i, tk.size(), tk) == 0) { best_len = tk.size(); best_id = id; break; }
     }
     if (best_id >= 0) {
       if (i > seg0) encode_plain(text.substr(seg0, i - seg0));

@@ -175,8 +175,9 @@ def bpe_json(tmp_path_factory):
     """A small byte-level BPE tokenizer.json with Qwen2's pre-tokeniser pattern and Qwen-style added tokens,
     trained with HuggingFace `tokenizers` (no real Qwen tokenizer exists offline)."""
     tokenizers = pytest.importorskip("tokenizers")
-    from tokenizers import Regex, Tokenizer, decoders, models, pre_tokenizers, trainers
+    from tokenizers import Regex, Tokenizer, decoders, models, normalizers, pre_tokenizers, trainers
     tok = Tokenizer(models.BPE())
+    tok.normalizer = normalizers.NFC()   # as in Qwen's tokenizer.json
     pat = r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"
     tok.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split(Regex(pat), behavior="isolated"),
                                                  pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)])
@@ -217,9 +218,35 @@ def test_tokenizer_encode_matches_hf(lib, bpe_json):
     texts = ["language English", "language Chinese", "language Japanese", "it's 2024! We'll see.\n\nNew line here.  two  spaces ",
              "IT'S  HE'LL they'RE I'VE i'm we'd 'tis", "tabs\tand\r\nCRLF \n \n", " leading and trailing   ", "a1b22c333 x_y-z (q)!?...",
              "你好，这是语音识别测试。", "こんにちは 12345 ...  spaces   ", "naïve café Ünïcödé straße ΑΒΓ абв", "全角　空白 and\u00a0nbsp\u2003em",
-             "٣٤٥ ½ ² Ⅷ numbers", "emoji 🙂🙂 mixed🙂text", "language English<asr_text>Hello there.<|im_end|>", "<|im_start|>user\n<asr_text>", "x<asr_text", ""]
+             "٣٤٥ ½ ² Ⅷ numbers", "emoji 🙂🙂 mixed🙂text", "language English<asr_text>Hello there.<|im_end|>", "<|im_start|>user\n<asr_text>", "x<asr_text", "",
+             # not NFC on input: decomposed accents, Hangul jamo, reordering of combining marks, singletons
+             "cafe\u0301 nai\u0308ve A\u030a \u212b \u2126", "\u1112\u1161\u11ab\u1100\u1173\u11af 한글", "a\u0323\u0302 a\u0302\u0323 \u1e69 s\u0307\u0323",
+             "\u0061\u0315\u0300\u05ae\u0300\u0062 \u0344 \u0958 \ufb1d", "<|im_start|>e\u0301<asr_text>o\u0308"]
     for t in texts:
         assert mine.encode(t) == hf.encode(t, add_special_tokens=False).ids, repr(t)
+
+
+def test_nfc_normaliser_matches_unicodedata(lib):
+    """The normaliser of tokenizer.rs:33-39 (NFC via the `tokenizers` crate) on its own: csrc/host_text.cpp normalize_nfc
+    against Python's unicodedata over every code point that has a canonical decomposition or a combining class (alone and
+    between two base letters), Hangul, and random mixed strings.  The generated tables record their Unicode versions."""
+    import random, unicodedata
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qwen3_asr_rs_amd", "csrc", "unicode_tables.h")).read()
+    assert f'kUnicodeNfcVersion[] = "{unicodedata.unidata_version}"' in hdr
+    assert 'kUnicodeCategoryLevel[] = "16.0"' in hdr            # \p{L} / \p{N} from a current UCD (regex module), not Unicode 13
+    interesting = [c for c in range(0x110000) if not 0xD800 <= c <= 0xDFFF and
+                   (unicodedata.combining(chr(c)) or (unicodedata.decomposition(chr(c)) and not unicodedata.decomposition(chr(c)).startswith("<")))]
+    assert len(interesting) > 2500
+    for i in range(0, len(interesting), 64):   # batches keep the ctypes round trips few
+        s = " ".join(chr(c) + "|a" + chr(c) + "e" + chr(c) for c in interesting[i:i + 64])
+        assert audio.normalize_nfc(s) == unicodedata.normalize("NFC", s), hex(interesting[i])
+    rng = random.Random(7)
+    pool = interesting + list(range(0x41, 0x7B)) + list(range(0xAC00, 0xAC00 + 600, 7)) + list(range(0x1100, 0x1113)) + \
+        list(range(0x1161, 0x1176)) + list(range(0x11A8, 0x11C3)) + [0x4F60, 0x597D, 0x1F642]
+    for _ in range(400):
+        s = "".join(chr(rng.choice(pool)) for _ in range(rng.randint(1, 24)))
+        assert audio.normalize_nfc(s) == unicodedata.normalize("NFC", s), [hex(ord(c)) for c in s]
+    assert audio.normalize_nfc("plain ASCII stays") == "plain ASCII stays"
 
 
 def test_parse_and_capitalize_match_oracle(lib):
