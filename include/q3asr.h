@@ -54,6 +54,10 @@ typedef struct q3a_dims {
 
 /* ---- load -------------------------------------------------------------------------------------- */
 
+/* Device selection of the CLI (src/main.rs:51-65: tch::Cuda::is_available / init_mlx): number of HIP devices this process
+ * can use, 0 when there is none (the library has no CPU path).  Never fails. */
+int32_t q3a_device_count(void);
+
 /* AsrInference::load (src/inference.rs:30-86): parse config.json, read model.safetensors or the
  * sharded index (src/weights.rs:10-58), build the bf16 device weight arena on GPU `device`. */
 int32_t q3a_engine_create(const char* model_dir, int32_t device, const q3a_opts* opts, q3a_engine** out);

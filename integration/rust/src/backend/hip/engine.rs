@@ -28,6 +28,7 @@ pub struct q3a_opts {
 #[link(name = "q3asr_hip")]
 extern "C" {
     pub fn q3a_opts_default(o: *mut q3a_opts);
+    pub fn q3a_device_count() -> i32;
     pub fn q3a_engine_create(model_dir: *const c_char, device: i32, opts: *const q3a_opts, out: *mut *mut q3a_engine) -> i32;
     pub fn q3a_engine_destroy(e: *mut q3a_engine);
     pub fn q3a_last_error(e: *const q3a_engine) -> *const c_char;
@@ -40,6 +41,9 @@ extern "C" {
     pub fn q3a_group_transcribe(g: *mut q3a_group, pcm16k: *const f32, n_samples: *const i64, b: i32, lang_prefix_ids: *const i32,
                                 n_prefix: i32, max_new: i32, fixed_new_tokens: i32, out_ids: *mut i32, stride: i32, out_lens: *mut i32) -> i32;
 }
+
+/// src/main.rs:51-65 for the `hip` feature: HIP devices visible to this process (0: none -- there is no CPU path).
+pub fn device_count() -> i32 { unsafe { q3a_device_count() } }
 
 fn msg(p: *const c_char) -> String {
     if p.is_null() { "unknown error".into() } else { unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned() }

@@ -150,8 +150,7 @@ impl Tensor {
 //     #[cfg(feature = "hip")]
 //     { crate::backend::hip::ops::add_inplace(&mut self.inner, &rhs.inner); }                // +=
 //
-// The two other places the backend leaks:
-//   * src/weights.rs:61-131  -- `load_safetensors` arm: `Tensor::from_hip(HipArray::from_bytes(bytes, dtype_code, shape, device))`
-//     followed by `.to_dtype(DType::Float32)` (the tch arm widens BF16/F16 to f32 on load, weights.rs:74-89);
-//   * src/audio_encoder.rs:227-259 -- the window mask: `Tensor::from_slice_f32(&mask_vals).reshape(&[1, 1, t, t]).to_device(device)`
-//     with 0.0 / f32::NEG_INFINITY entries (no `where_self` needed).
+// The other places the backend leaks have their own files next to this one:
+//   * src/weights.rs:61-131        -> weights_hip_arm.rs        (`load_safetensors` arm)
+//   * src/audio_encoder.rs:227-259 -> audio_encoder_hip_arm.rs  (window mask without `where_self`)
+//   * src/main.rs:51-65, lib.rs, Cargo.toml, build.rs -> main_hip_arm.rs

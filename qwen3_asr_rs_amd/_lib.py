@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("Q3A_LIB") or os.path.join(HERE, "lib", "libq3asr_hip.
 
 # every symbol include/q3asr.h declares (tests check the exports against the header text)
 SYMBOLS = [
-    "q3a_opts_default", "q3a_engine_create", "q3a_arena_bytes", "q3a_arena_pack", "q3a_engine_create_from_arena",
+    "q3a_opts_default", "q3a_device_count", "q3a_engine_create", "q3a_arena_bytes", "q3a_arena_pack", "q3a_engine_create_from_arena",
     "q3a_engine_destroy", "q3a_last_error", "q3a_get_dims", "q3a_weights_rounded", "q3a_num_frames", "q3a_num_audio_tokens",
     "q3a_build_prompt", "q3a_mel", "q3a_encode", "q3a_prefill", "q3a_decode_step", "q3a_set_next_tokens",
     "q3a_upload_pcm", "q3a_run_resident", "q3a_fetch_ids", "q3a_transcribe_batch", "q3a_stage_timings",
@@ -65,6 +65,7 @@ def load() -> C.CDLL:
     i32p, i64p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint8)
     sig = {
         "q3a_opts_default": (None, [C.POINTER(Opts)]),
+        "q3a_device_count": (i32, []),
         "q3a_engine_create": (i32, [C.c_char_p, i32, C.POINTER(Opts), C.POINTER(P)]),
         "q3a_arena_bytes": (i32, [C.c_char_p, C.POINTER(u64)]),
         "q3a_arena_pack": (i32, [C.c_char_p, P, u64]),

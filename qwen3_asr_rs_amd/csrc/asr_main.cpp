@@ -45,7 +45,9 @@ int main(int argc, char** argv) {
   if (!exists(model_path)) return die(std::string("Model directory not found: ") + model_path);  // main.rs:43-45
   if (!exists(audio_file)) return die(std::string("Audio file not found: ") + audio_file);       // main.rs:46-48
 
-  logf(1, "Using HIP device 0 (MI355X / gfx950)");
+  const int n_dev = q3a_device_count();  // main.rs:51-65
+  if (n_dev <= 0) return die("No HIP device available (libq3asr_hip has no CPU path)");
+  logf(1, "Using HIP device 0 of %d (MI355X / gfx950)", n_dev);
   logf(1, "Loading model from \"%s\"", model_path);
   q3a_opts opts;
   q3a_opts_default(&opts);

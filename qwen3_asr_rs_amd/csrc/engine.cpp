@@ -1070,6 +1070,11 @@ static int32_t create_impl(const char* model_dir, int32_t device, void* dev_aren
   }
 }
 
+int32_t q3a_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int32_t q3a_engine_create(const char* model_dir, int32_t device, const q3a_opts* opts, q3a_engine** out) {
   return create_impl(model_dir, device, nullptr, 0, opts, out);
 }
