@@ -968,8 +968,24 @@ struct q3a_engine {
     timings.decode_steps = steps; timings.batch = B; timings.total_audio_tokens = total_T; timings.total_prompt_tokens = total_P;
   }
 
+  // Fused qkv + attention launch (experimental knob): a wait on the in-XCD arrival counter that ran out means partial q/k/v
+  // entered the attention -- the ids are wrong, so every way out of the engine fails instead of returning them.
+  void check_fused_launch() {
+    if (!k_fuse_qkv_attn || !xcd_sync.p) return;
+    unsigned w[8 * 64];
+    HIPCHK(hipMemcpy(w, xcd_sync.p, sizeof(w), hipMemcpyDeviceToHost));
+    unsigned n = 0;
+    for (int g = 0; g < 8; ++g) n += w[g * 64 + 48];
+    if (n) {
+      HIPCHK(hipMemset(xcd_sync.p, 0, 2 * 8 * 64 * 4));
+      fail("fused qkv + attention launch: " + std::to_string(n) + " in-XCD wait(s) ran out (workgroups of a kv head not co-located or "
+           "stalled); the generated ids are invalid -- run with q3a_debug_set(\"fuse_qkv_attn\", 0)");
+    }
+  }
+
   void fetch_ids(int32_t* out, int stride, int32_t* out_lens) {
     if (!have_prefill) fail("q3a_fetch_ids: nothing generated");
+    check_fused_launch();
     std::vector<int> all((size_t)B * max_new), sc(B);
     HIPCHK(hipMemcpy(all.data(), out_ids.p, all.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(sc.data(), step_count.p, (size_t)B * 4, hipMemcpyDeviceToHost));
@@ -1214,6 +1230,7 @@ int32_t q3a_decode_step(q3a_engine* e, int32_t* next_ids, uint8_t* done, float* 
   e->decode_steps(1);
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipGetLastError());
+  e->check_fused_launch();
   if (next_ids) HIPCHK(hipMemcpy(next_ids, e->next_tok.p, (size_t)e->B * 4, hipMemcpyDeviceToHost));
   if (done) HIPCHK(hipMemcpy(done, e->done.p, (size_t)e->B, hipMemcpyDeviceToHost));
   if (logits_out) HIPCHK(hipMemcpy(logits_out, e->logits.p, (size_t)e->B * e->d.vocab * 4, hipMemcpyDeviceToHost));

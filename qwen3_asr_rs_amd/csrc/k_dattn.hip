@@ -274,7 +274,8 @@ struct QkvFuse {
   const float* x; const float* rms_w; float eps;   // [K] hidden row of the token, input-norm weight
   const uint16_t* W; const float* bias; int K;     // [(n_q + 2 n_kv) * 128][K]
   float* qkv_out;                                   // = DecodeAttnArgs::qkv
-  unsigned* sync;                                   // [8][64] words: [g][0] arrivals, [g][32] departures
+  unsigned* sync;                                   // [8][64] words: [g][0] arrivals, [g][32] departures, [g][48] STICKY count of
+                                                    // waits that ran out (never cleared by the kernel: the host fails on it)
   unsigned* debug;                                  // optional [8][64]: [g][slot] = XCC_ID the workgroup ran on, [g][32] = waits that
                                                     // ran out, [g][33 + split] = arrivals seen when they did
 };
@@ -355,7 +356,10 @@ __device__ __forceinline__ void xcd_wait(unsigned* cnt, unsigned members, unsign
     // waits that ran out at 29..31 of 32 arrivals in every second launch.
     while ((seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < members && ++spins < (1 << 16))
       __builtin_amdgcn_s_sleep(1);
-    if (dbg && seen < members) { atomicAdd(dbg + 32, 1u); dbg[33 + slot] = seen; }
+    if (seen < members) {  // the wait ran out (placement not one kv head per XCD, or a stalled peer): the result is invalid
+      atomicAdd(cnt + 48, 1u);
+      if (dbg) { atomicAdd(dbg + 32, 1u); dbg[33 + slot] = seen; }
+    }
     if (__hip_atomic_fetch_add(cnt + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == waiters - 1) {  // last one out
       __hip_atomic_exchange(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       __hip_atomic_exchange(cnt + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -924,6 +924,10 @@ int32_t q3a_op_to_device(q3a_array** out, const q3a_array* a, int32_t device, q3
       OHIP(hipMemcpy(r->base(), c->data(), bytes, hipMemcpyDeviceToHost));
     } else {
       OHIP(hipStreamSynchronize(sd(a)));
+      // the destination block may be a recycled one whose last user is still queued on the DESTINATION device's
+      // (non-blocking) ops stream: drain that stream before the peer copy lands in it
+      OHIP(hipSetDevice(device));
+      OHIP(hipStreamSynchronize(stream_of(device)));
       OHIP(hipMemcpyPeer(r->base(), device, c->data(), a->device, bytes));
     }
   }

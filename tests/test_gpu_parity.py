@@ -333,6 +333,31 @@ def test_native_group_one_gpu_through_rccl(tiny_dir, monkeypatch):
         HipGroup(tiny_dir, 64)
 
 
+def test_native_group_on_every_visible_gpu(tiny_dir):
+    """The >1-rank start-up of q3a_group_create (ncclCommInitAll over N devices, ncclGroupStart / one ncclBroadcast per rank
+    / ncclGroupEnd, csrc/group.cpp) and the one-thread-per-GPU q3a_group_transcribe: runs whenever this box shows at
+    least two HIP devices (the 1-GPU test boxes skip it; an 8-GPU node exercises it without anybody editing a flag).
+    Contiguous partition, ids equal to one engine's on the same utterances, fewer utterances than GPUs tolerated."""
+    from qwen3_asr_rs_amd import _lib
+    from qwen3_asr_rs_amd.engine import HipGroup
+    n = int(_lib.load().q3a_device_count())
+    if n < 2:
+        pytest.skip(f"{n} HIP device(s) visible: the multi-rank RCCL path needs at least 2")
+    n = min(n, 8)
+    clips = [synthetic.synthetic_clip(60 + i, 1.0 + 0.21 * (i % 5)) for i in range(2 * n + 1)]
+    eng = HipEngine(tiny_dir, 0, max_new_tokens=8)
+    ref = eng.transcribe_batch(clips, None, max_new=5, fixed_new_tokens=5)
+    eng.close()
+    grp = HipGroup(tiny_dir, n, max_new_tokens=8)
+    assert grp.size == n and grp.used_rccl
+    assert grp.transcribe_batch(clips, None, max_new=5, fixed_new_tokens=5) == ref
+    assert grp.transcribe_batch(clips[:1], None, max_new=5, fixed_new_tokens=5) == ref[:1]   # ranks 1.. get nothing
+    grp.close()
+    grp = HipGroup(tiny_dir, 2, devices=[n - 1, 0], max_new_tokens=8)   # explicit device list, root on the last GPU
+    assert grp.size == 2 and grp.transcribe_batch(clips[:5], None, max_new=5, fixed_new_tokens=5) == ref[:5]
+    grp.close()
+
+
 def test_long_audio_many_windows_and_long_context(tiny_dir):
     """61.3 s clip: 62 chunks -> 8 attention windows in the encoder, prompt of ~800 tokens -> the decode step
     runs over 7+ key splits (flash-decoding merge in the o_proj GEMV); plus an exact multiple of the chunk size."""
