@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
 
   const int n_dev = q3a_device_count();  // main.rs:51-65
   if (n_dev <= 0) return die("No HIP device available (libq3asr_hip has no CPU path)");
-  logf(1, "Using HIP device 0 of %d (MI355X / gfx950)", n_dev);
+  logf(1, "Using HIP device 0 of %s (MI355X / gfx950)", std::to_string(n_dev));
   logf(1, "Loading model from \"%s\"", model_path);
   q3a_opts opts;
   q3a_opts_default(&opts);

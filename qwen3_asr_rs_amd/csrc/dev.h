@@ -3,6 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Phase stamps for tools/phase_probe.hip (probe builds define Q3A_STAMP; the product library never does): thread 0 of a
+// workgroup records the 100 MHz wall clock at up to 8 phase boundaries of the kernel.
+#ifdef Q3A_STAMP
+#define Q3A_STAMP_FIELD unsigned long long* stamp = nullptr;  /* [workgroup][8], null = off */
+#define Q3A_STAMP_AT(ptr, wg, slot) do { if ((ptr) && threadIdx.x == 0) (ptr)[(size_t)(wg) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define Q3A_STAMP_FIELD
+#define Q3A_STAMP_AT(ptr, wg, slot) do { } while (0)
+#endif
+
 namespace q3a {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;  // MFMA 16x16x32 bf16 A/B operand (4 VGPRs)

@@ -417,6 +417,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   __shared__ float co[DA_WAVES][GROUP][128];
   const int kvh = blockIdx.x, s = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int stamp_wg = blockIdx.y * gridDim.x + blockIdx.x;
+  Q3A_STAMP_AT(a.stamp, stamp_wg, 0);  // entry
   const int sub = lane % LPK, kq = lane / LPK;
   const int qkv_dim = (a.n_q + 2 * a.n_kv) * 128;
   const float* row = a.qkv + (size_t)s * qkv_dim;
@@ -456,6 +458,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   if constexpr (RING > 2) load_tile(2, kr2, vr2);
   if constexpr (RING > 3) load_tile(3, kr3, vr3);
   __builtin_amdgcn_sched_barrier(0);
+  Q3A_STAMP_AT(a.stamp, stamp_wg, 1);  // q/k/v row + first tiles requested
   const int pos = a.pos[s];
   const int n_tiles = pos / TILE + 1;  // tiles that hold at least one key <= pos
 
@@ -481,6 +484,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
     KvIo<KVT>::store(&v_s[lane + 64], x2);
   }
   __syncthreads();
+  Q3A_STAMP_AT(a.stamp, stamp_wg, 2);  // q / new k / new v in LDS
 
   const float inv_scale = 1.0f / a.scale_div;
   auto expw = [](float x) { return sizeof(KVT) == 4 ? expf(x) : __expf(x); };
@@ -585,6 +589,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
       }
     }
   }
+  Q3A_STAMP_AT(a.stamp, stamp_wg, 3);  // every tile consumed
   // fold the KPI key columns of the wave (lanes with equal `sub`), then the waves through LDS
 #pragma unroll
   for (int g = 0; g < GROUP; ++g) {
@@ -605,6 +610,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
     }
   }
   __syncthreads();
+  Q3A_STAMP_AT(a.stamp, stamp_wg, 4);  // wave partials in LDS
   if (wave < GROUP) {
     const int g = wave;
     float M = -INFINITY;
@@ -635,6 +641,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
       a.out[(size_t)s * a.n_q * 128 + head * 128 + lane + 64] = o1;
     }
   }
+  Q3A_STAMP_AT(a.stamp, stamp_wg, 5);
 }
 
 // merge of the split partials into [S][n_q*128] (only the GEMM decode path needs it as a separate launch)

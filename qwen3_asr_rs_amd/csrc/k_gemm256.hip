@@ -116,6 +116,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
                                                          RopeKvArgs rk) {
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * G_BUF];  // the ONLY LDS object of this kernel
 
+  Q3A_STAMP_AT(ep.stamp, blockIdx.x, 0);  // entry
   const int tiles_m = (M + G_BM - 1) / G_BM, tiles_n = (N + G_BN - 1) / G_BN;
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
   Q3A_WAIT_VM(8);  // A-m0(0), B-n0(0) have landed (this wave's part)
   Q3A_BARRIER();
   if (wr == 1) Q3A_BARRIER();  // the second wave group runs one barrier behind the first
+  Q3A_STAMP_AT(ep.stamp, blockIdx.x, 1);  // first staging units landed: the K loop starts
 
   bf16x8_t af[8], b0f[4], b1f[4];
 
@@ -298,6 +300,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
     tile(t + 1, std::false_type{}, std::false_type{});
   }
   if (wr == 0) Q3A_BARRIER();  // balance the extra barrier of the second group: every wave is past its last LDS read
+  Q3A_STAMP_AT(ep.stamp, blockIdx.x, 2);  // K loop done
 
   // ---- epilogue: the wave's 128 x 64 tile goes through its private 16 KiB of LDS in two 64-row passes, so that global
   // memory sees whole rows: 256 B (fp32) / 128 B (bf16) contiguous per row instead of the 64-B column slices of the MFMA
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
 #pragma unroll
         for (int r = 0; r < 4; ++r) stg[(i * 16 + row_in + r) * 64 + j * 16 + col_in] = acc[h * 4 + i][j][r];
     const int mrow0 = m0 + wr * 128 + h * 64;
+    Q3A_STAMP_AT(ep.stamp, blockIdx.x, 3 + h * 2);  // pass h staged in LDS (wave 0)
     if constexpr (ROPE) {
       // A 128-wide head = the 64-column tiles of the wave pair (wc, wc ^ 1): column c of the even wave and column c of the
       // odd wave are the rotate_half partners (dims c, c + 64).  Both halves are staged; after a workgroup barrier a lane
@@ -433,6 +437,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
         }
       }
     }
+    Q3A_STAMP_AT(ep.stamp, blockIdx.x, 4 + h * 2);  // pass h stored (wave 0)
   }
 }
 

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   __shared__ float part[SK_WAVES][TILES][SH][16][17];  // [k-slice][tile][seq half][row][sequence] (+1 pad)
   __shared__ float ssp[SK_WAVES][SH][16];              // XMODE 1: sum(x^2) of each sequence over the wave's K slice
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  Q3A_STAMP_AT(a.stamp, blockIdx.x, 0);  // entry
   const int l15 = lane & 15, kc = lane >> 4;  // row / sequence inside the fragment, k-chunk (8 elements)
   int n0 = blockIdx.x * 16 * TILES, hsel = 0, part_row = blockIdx.x;
   if (QS) {  // block b: XCD b & 7; consecutive same-XCD blocks alternate the sequence half
@@ -198,7 +199,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
         w1[u] = *reinterpret_cast<const float4*>(nrow + ko + 4);
       }
     }
+    Q3A_STAMP_AT(a.stamp, blockIdx.x, 1);  // every load of the pass requested
     if (WLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA is not in the compiler's load bookkeeping
+    Q3A_STAMP_AT(a.stamp, blockIdx.x, 2);  // (WLDS) weights landed
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const bool live = kb + u < ks1;
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   }
   return;
 #endif
+  Q3A_STAMP_AT(a.stamp, blockIdx.x, 3);  // MFMAs issued (their operands have arrived)
   // D[row i][sequence j] of v_mfma_f32_16x16x32: j = lane&15, i = (lane>>4)*4 + r
 #pragma unroll
   for (int t = 0; t < TILES; ++t)
@@ -262,6 +266,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     }
   }
   __syncthreads();
+  Q3A_STAMP_AT(a.stamp, blockIdx.x, 4);  // partial tiles of all waves in LDS
   // ---- fixed-order reduction of the K-slices + epilogue: thread -> (row i, sequence s) ----
   // 16 rows x 32 sequences = 512 threads; 16 consecutive lanes own the 16 consecutive output columns of one sequence
   // (64-B runs; with the sequence as the fast index every lane hit its own line: 4 KB stride)
@@ -299,6 +304,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
       const float q = QS ? row8_sum(y * y) : row16_sum(y * y);  // this block's 16 (8) columns of sequence s
       if (i == 0 && live_s) a.next_ss[(size_t)part_row * 32 + s] = q;
     }
+    Q3A_STAMP_AT(a.stamp, blockIdx.x, 5);  // epilogue stores issued
   } else {  // rows n0..n0+15 = gate, n0+16..n0+31 = up of logical rows n0/2 .. n0/2+15
     if (!live_s || n0 + 16 + i >= a.N) return;
     float g = v[0], u = v[TILES - 1];
@@ -306,6 +312,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     const float y = silu_f(g) * u;
     if (a.out16) a.out16[a.out16_frag ? skinny_frag_index(s, (n0 >> 1) + i) : (size_t)s * a.ldo + (n0 >> 1) + i] = (uint16_t)f32_to_bf16_bits(y);
     else a.out[(size_t)s * a.ldo + (n0 >> 1) + i] = y;
+    Q3A_STAMP_AT(a.stamp, blockIdx.x, 5);
   }
 }
 

@@ -6,6 +6,14 @@
 
 #include <atomic>
 
+#ifndef Q3A_STAMP_FIELD  // (dev.h defines it for device code; host-only translation units get the same layout)
+#ifdef Q3A_STAMP
+#define Q3A_STAMP_FIELD unsigned long long* stamp = nullptr;
+#else
+#define Q3A_STAMP_FIELD
+#endif
+#endif
+
 namespace q3a {
 
 // ---- GEMM (k_gemm.hip) -----------------------------------------------------------------------------
@@ -19,6 +27,7 @@ struct GemmEpilogue {
   const int* rowmap = nullptr;   // GEMM row m -> output row (negative: drop the row); null = identity
   const float* addend = nullptr; // [addend_period][ldo] added before the activation (positional embedding)
   int addend_period = 1;
+  Q3A_STAMP_FIELD
 };
 // Y = X[M][K](fp32, row stride lda) . W[N][K]^T(bf16).  glu: W rows are [16 gate|16 up] blocks, out has N/2 columns.
 const char* launch_gemm(const float* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
@@ -187,6 +196,7 @@ struct SkinnyArgs {
   // N / 8 partial rows instead of N / 16 -- the caller sizes its buffers and the consumer's ss_nparts accordingly
   int qsplit;
   int qs_halves;  // (set by the launcher: 16-sequence halves per row tile)
+  Q3A_STAMP_FIELD
 };
 // the same producer duty for kernels that write a whole row of the residual stream (token embedding)
 struct NextNormOut {
@@ -224,6 +234,7 @@ struct DecodeAttnArgs {
   float* out;                  // [S][n_q*128] fp32 (precise mode) ...
   uint16_t* out16;             // ... or bf16 (default mode), row-major or, with out_frag, in skinny_frag_index order
   int out_frag;
+  Q3A_STAMP_FIELD
 };
 constexpr int DATTN_KEYS_PER_SPLIT_BF16 = 128, DATTN_KEYS_PER_SPLIT_F32 = 128;
 inline int dattn_keys_per_split(bool kv_f32) { return kv_f32 ? DATTN_KEYS_PER_SPLIT_F32 : DATTN_KEYS_PER_SPLIT_BF16; }
