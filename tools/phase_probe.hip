@@ -1,0 +1,243 @@
+// Phase probe (not product code): WHERE inside the latency-bound kernels of the batched decode step and inside a
+// gemm256 tile does the time go?  The product kernels are compiled with -DQ3A_STAMP: thread 0 of every workgroup
+// records the 100 MHz wall clock at the phase boundaries marked in k_skinny.hip / k_dattn.hip / k_gemm256.hip.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DQ3A_STAMP -I qwen3_asr_rs_amd/csrc -o build/tools/phase_probe tools/phase_probe.hip
+//   build/tools/phase_probe            (on the GPU box)
+//
+// Part 1: one decoder layer of the 0.6B model at 32 sequences x ~500 keys as the product launches it (skinny qkv ->
+// batched attention -> skinny o -> skinny gate/up -> skinny down), 28 layers x several steps replayed from a hipGraph over
+// 1 GiB of distinct weights / KV (no cache reuse between layers), every launch with its own stamp rows.  Reported per
+// kernel: wall time per layer from HIP events, and from the stamps the gap to the previous kernel (last workgroup out ->
+// first workgroup in), the start ramp (first -> last workgroup in), the mean duration of every phase, and the kernel's
+// own span.
+// Part 2: gemm256 on the encoder / prefill shapes at 32 clips: per-tile phase means (prologue, K loop, the two epilogue
+// passes) and the makespan of the launch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "k_dattn.hip"
+#include "k_gemm16.hip"
+#include "k_gemm256.hip"
+#include "k_skinny.hip"
+
+namespace q3a {
+Knobs& knobs() { static Knobs k; return k; }
+// (k_gemm256.hip's fused-epilogue launcher refers to it for its split remainder; not used here)
+const char* launch_qknorm_rope_kv(const RopeKvArgs&, int, bool, hipStream_t) { return "phase_probe: not linked"; }
+}  // namespace q3a
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+#define KCHK(x) do { const char* m_ = (x); if (m_) { printf("launch error: %s (line %d)\n", m_, __LINE__); exit(1); } } while (0)
+
+typedef unsigned long long u64;
+
+struct Launch { int kind; int wgs; size_t off; };  // stamp rows of one launch: [off, off + wgs)
+
+static void summarize(const char* title, const std::vector<const char*>& kind_names, const std::vector<std::vector<const char*>>& phase_names,
+                      const std::vector<Launch>& ls, const std::vector<u64>& st, int skip_first) {
+  const double tick_us = 0.01;  // wall_clock64: 100 MHz
+  printf("\n== %s ==\n", title);
+  const int nk = (int)kind_names.size();
+  std::vector<double> gap(nk, 0), ramp(nk, 0), span(nk, 0);
+  std::vector<std::vector<double>> ph(nk, std::vector<double>(8, 0));
+  std::vector<int> cnt(nk, 0);
+  u64 prev_end = 0;
+  for (size_t li = 0; li < ls.size(); ++li) {
+    const Launch& l = ls[li];
+    const int np = (int)phase_names[l.kind].size();  // stamps 0 .. np
+    u64 s0min = ~0ull, s0max = 0, endmax = 0;
+    std::vector<double> sum(8, 0);
+    for (int w = 0; w < l.wgs; ++w) {
+      const u64* r = &st[(l.off + w) * 8];
+      s0min = std::min(s0min, r[0]); s0max = std::max(s0max, r[0]); endmax = std::max(endmax, r[np]);
+      for (int p = 0; p < np; ++p) sum[p] += (double)(r[p + 1] - r[p]);
+    }
+    if ((int)li >= skip_first) {
+      cnt[l.kind]++;
+      if (prev_end) gap[l.kind] += (double)((long long)s0min - (long long)prev_end) * tick_us;
+      ramp[l.kind] += (double)(s0max - s0min) * tick_us;
+      span[l.kind] += (double)(endmax - s0min) * tick_us;
+      for (int p = 0; p < np; ++p) ph[l.kind][p] += sum[p] / l.wgs * tick_us;
+    }
+    prev_end = endmax;
+  }
+  for (int k = 0; k < nk; ++k) {
+    if (!cnt[k]) continue;
+    printf("%-34s launches %5d  gap-from-previous %6.2f us  start ramp %5.2f  span(first in -> last out) %6.2f us\n", kind_names[k], cnt[k],
+           gap[k] / cnt[k], ramp[k] / cnt[k], span[k] / cnt[k]);
+    printf("    mean per workgroup:");
+    for (size_t p = 0; p < phase_names[k].size(); ++p) printf("  %s %.2f", phase_names[k][p], ph[k][p] / cnt[k]);
+    printf("  (us)\n");
+  }
+}
+
+int main(int argc, char** argv) {
+  const bool do_layer = argc < 2 || strstr(argv[1], "layer"), do_gemm = argc < 2 || strstr(argv[1], "gemm");
+  hipStream_t s;
+  CHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  KCHK(q3a::skinny_init());
+  const size_t WB = (size_t)12 << 29;  // 6 GiB pool (bf16 elements' worth of pool (elements, not bytes, below): weights and KV of 56 successive layers walk through it
+  uint16_t* pool;
+  CHK(hipMalloc(&pool, WB));
+  CHK(hipMemset(pool, 0x3c, WB));  // bf16 0x3c3c = 0.0115: finite everywhere
+  const size_t pool_elems = WB / 2;
+
+  if (do_layer) {
+    // ---------------- part 1: the batched decode layer ----------------
+    const int S = 32, H = 1024, I = 3072, NQ = 16, NKV = 8, QD = NQ * 128, QKV = (NQ + 2 * NKV) * 128, MAXCTX = 576, POS = 500;
+    const int L = 28, STEPS = 6;
+    // per-layer slab in the pool: qkv_w, o_w, gu_w, down_w, K cache, V cache
+    const size_t e_qkv = (size_t)QKV * H, e_o = (size_t)H * QD, e_gu = (size_t)2 * I * H, e_dn = (size_t)H * I, e_kv = (size_t)S * NKV * MAXCTX * 128;
+    const size_t slab = e_qkv + e_o + e_gu + e_dn + 2 * e_kv;
+    if (slab * L * 2 > pool_elems) { printf("pool too small: %zu > %zu elements\n", slab * L * 2, pool_elems); return 1; }
+    float *x, *qkv, *rope, *nw;
+    uint16_t *nn_x, *ctx16, *act16;
+    float* nn_ss;
+    int* pos;
+    CHK(hipMalloc(&x, (size_t)S * H * 4)); CHK(hipMalloc(&qkv, (size_t)S * QKV * 4)); CHK(hipMalloc(&rope, (size_t)S * 128 * 4)); CHK(hipMalloc(&nw, 4096 * 4));
+    CHK(hipMalloc(&nn_x, (size_t)32 * H * 2)); CHK(hipMalloc(&ctx16, (size_t)32 * QD * 2)); CHK(hipMalloc(&act16, (size_t)32 * I * 2));
+    CHK(hipMalloc(&nn_ss, (size_t)(H / 8) * 32 * 4)); CHK(hipMalloc(&pos, S * 4));
+    CHK(hipMemset(x, 0, (size_t)S * H * 4)); CHK(hipMemset(qkv, 0, (size_t)S * QKV * 4)); CHK(hipMemset(nn_x, 0, (size_t)32 * H * 2));
+    CHK(hipMemset(ctx16, 0, (size_t)32 * QD * 2)); CHK(hipMemset(act16, 0, (size_t)32 * I * 2)); CHK(hipMemset(nn_ss, 0, (size_t)(H / 8) * 32 * 4));
+    {
+      std::vector<float> ones(4096, 1.0f), rc((size_t)S * 128);
+      for (size_t i = 0; i < rc.size(); ++i) rc[i] = (i % 128) < 64 ? 1.0f : 0.0f;  // cos = 1, sin = 0
+      std::vector<int> p(S, POS);
+      CHK(hipMemcpy(nw, ones.data(), 4096 * 4, hipMemcpyHostToDevice));
+      CHK(hipMemcpy(rope, rc.data(), rc.size() * 4, hipMemcpyHostToDevice));
+      CHK(hipMemcpy(pos, p.data(), S * 4, hipMemcpyHostToDevice));
+    }
+    const int wg_qkv = QKV / 16, wg_att = S * NKV, wg_o = (H / 8) * 2, wg_gu = 2 * I / 32, wg_dn = (H / 8) * 2;
+    const int per_layer = wg_qkv + wg_att + wg_o + wg_gu + wg_dn;
+    const size_t rows = (size_t)per_layer * L * STEPS;
+    u64* stamps;
+    CHK(hipMalloc(&stamps, rows * 8 * sizeof(u64)));
+    CHK(hipMemset(stamps, 0, rows * 8 * sizeof(u64)));
+    std::vector<Launch> ls;
+    const int nparts = H / 8;
+    auto layer = [&](int idx, bool record, bool stamped) {
+      uint16_t* base = pool + (size_t)(idx % (2 * L)) * slab;
+      const uint16_t *w_qkv = base, *w_o = w_qkv + e_qkv, *w_gu = w_o + e_o, *w_dn = w_gu + e_gu;
+      uint16_t *kc = const_cast<uint16_t*>(w_dn) + e_dn, *vc = kc + e_kv;
+      size_t off = (size_t)idx * per_layer;
+      auto rec = [&](int kind, int wgs) -> u64* { u64* p = stamped ? stamps + off * 8 : nullptr; if (record) ls.push_back({kind, wgs, off}); off += wgs; return p; };
+      q3a::SkinnyArgs q{};
+      q.x = x; q.ldx = H; q.S = S; q.eps = 1e-6f; q.W = w_qkv; q.N = QKV; q.K = H; q.xw16f = nn_x; q.ss_parts = nn_ss; q.ss_nparts = nparts;
+      q.mode = 0; q.out = qkv; q.ldo = QKV; q.stamp = rec(0, wg_qkv);
+      KCHK(q3a::launch_skinny(q, false, s));
+      q3a::DecodeAttnArgs da{};
+      da.qkv = qkv; da.pos = pos; da.eps = 1e-6f; da.rope_cur = rope; da.q_norm = nw; da.k_norm = nw; da.kcache = kc; da.vcache = vc;
+      da.n_q = NQ; da.n_kv = NKV; da.max_ctx = MAXCTX; da.scale_div = 11.3137f; da.out16 = ctx16; da.out_frag = 1; da.stamp = rec(1, wg_att);
+      KCHK(q3a::launch_decode_attn_batched(da, S, false, s));
+      q3a::SkinnyArgs o{};
+      o.x = reinterpret_cast<float*>(ctx16); o.x16 = ctx16; o.x16_frag = 1; o.ldx = QD; o.S = S; o.W = w_o; o.N = H; o.K = QD; o.mode = 1; o.out = x; o.ldo = H; o.resid = x;
+      o.next_w = nw; o.next_xw16f = nn_x; o.next_ss = nn_ss; o.qsplit = 1; o.stamp = rec(2, wg_o);
+      KCHK(q3a::launch_skinny(o, false, s));
+      q3a::SkinnyArgs u{};
+      u.x = x; u.ldx = H; u.S = S; u.eps = 1e-6f; u.W = w_gu; u.N = 2 * I; u.K = H; u.xw16f = nn_x; u.ss_parts = nn_ss; u.ss_nparts = nparts;
+      u.mode = 2; u.out = reinterpret_cast<float*>(act16); u.out16 = act16; u.out16_frag = 1; u.ldo = I; u.stamp = rec(3, wg_gu);
+      KCHK(q3a::launch_skinny(u, false, s));
+      q3a::SkinnyArgs d{};
+      d.x = reinterpret_cast<float*>(act16); d.x16 = act16; d.x16_frag = 1; d.ldx = I; d.S = S; d.W = w_dn; d.N = H; d.K = I; d.mode = 1; d.out = x; d.ldo = H; d.resid = x;
+      d.next_w = nw; d.next_xw16f = nn_x; d.next_ss = nn_ss; d.qsplit = 1; d.stamp = rec(4, wg_dn);
+      KCHK(q3a::launch_skinny(d, false, s));
+    };
+    for (int stamped = 1; stamped >= 0; --stamped) {
+      hipGraph_t g;
+      hipGraphExec_t ge;
+      CHK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+      for (int i = 0; i < L * STEPS; ++i) layer(i, stamped == 1 && ls.size() < (size_t)5 * L * STEPS, stamped == 1);
+      CHK(hipStreamEndCapture(s, &g));
+      CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      hipEvent_t a, b;
+      CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+      CHK(hipGraphLaunch(ge, s));
+      CHK(hipStreamSynchronize(s));
+      float best = 1e30f;
+      for (int r = 0; r < 4; ++r) {
+        CHK(hipEventRecord(a, s)); CHK(hipGraphLaunch(ge, s)); CHK(hipEventRecord(b, s)); CHK(hipStreamSynchronize(s));
+        float ms; CHK(hipEventElapsedTime(&ms, a, b)); best = std::min(best, ms);
+      }
+      printf("batched decode layer (32 seq x %d keys, 0.6B dims), %s: %.2f us per layer (%.1f us per 28-layer step)\n", POS + 1,
+             stamped ? "stamped build, stamps on" : "stamped build, stamps off (null pointer)", best * 1e3 / (L * STEPS), best * 1e3 / STEPS);
+      CHK(hipGraphExecDestroy(ge)); CHK(hipGraphDestroy(g));
+      if (stamped) {
+        std::vector<u64> h(rows * 8);
+        CHK(hipMemcpy(h.data(), stamps, h.size() * sizeof(u64), hipMemcpyDeviceToHost));
+        summarize("phases of the batched decode layer (last replay)",
+                  {"skinny qkv (256 wg, 16 rows)", "decode_attn_batched (256 wg)", "skinny o (QS, 256 wg)", "skinny gate/up (192 wg, 32 rows)", "skinny down (QS, 256 wg)"},
+                  {{"issue", "wait", "mfma", "to-lds+barrier", "reduce+store"}, {"issue", "qkv-row+barrier", "tiles", "fold+barrier", "merge+store"},
+                   {"issue", "wait", "mfma", "to-lds+barrier", "reduce+store"}, {"issue", "wait", "mfma", "to-lds+barrier", "reduce+store"},
+                   {"issue", "wait", "mfma", "to-lds+barrier", "reduce+store"}},
+                  ls, h, 5 * L);
+      }
+    }
+  }
+
+  if (do_gemm) {
+    // ---------------- part 2: gemm256 tiles ----------------
+    struct Shape { const char* name; int M, N, K; int epi; };  // epi: 0 bf16 out + bias, 1 bf16 out + bias + GELU, 2 fp32 out + bias + residual
+    const Shape shapes[] = {{"enc qkv  12480 x 2688 x 896  (bf16 out)", 12480, 2688, 896, 0}, {"enc fc1  12480 x 3584 x 896  (bf16 out, GELU)", 12480, 3584, 896, 1},
+                            {"enc out  12480 x  896 x 896  (fp32 residual)", 12480, 896, 896, 2}, {"enc fc2  12480 x  896 x 3584 (fp32 residual)", 12480, 896, 3584, 2},
+                            {"dec o    12960 x 1024 x 2048 (fp32 residual)", 12960, 1024, 2048, 2}, {"square    4096 x 4096 x 4096 (bf16 out)", 4096, 4096, 4096, 0}};
+    uint16_t* X = pool;                      // activations
+    uint16_t* W = pool + ((size_t)1 << 28);  // weights, 512 MiB further on
+    float *out32, *bias;
+    uint16_t* out16;
+    CHK(hipMalloc(&out32, (size_t)12960 * 4096 * 4)); CHK(hipMalloc(&out16, (size_t)12960 * 4096 * 2)); CHK(hipMalloc(&bias, 8192 * 4));
+    CHK(hipMemset(out32, 0, (size_t)12960 * 4096 * 4)); CHK(hipMemset(bias, 0, 8192 * 4));
+    u64* stamps;
+    const int max_tiles = 1024;
+    CHK(hipMalloc(&stamps, (size_t)max_tiles * 8 * sizeof(u64)));
+    q3a::knobs().gemm256_min_tiles = 0;
+    setenv("Q3A_GEMM256_SPLIT_REM", "0", 1);  // every tile in ONE gemm256 launch: the phase means are per tile of that launch
+    for (const Shape& sh : shapes) {
+      const int tiles = ((sh.M + 255) / 256) * ((sh.N + 255) / 256);
+      q3a::GemmEpilogue ep;
+      ep.ldo = sh.N; ep.bias = bias;
+      if (sh.epi == 2) { ep.out = out32; ep.resid = out32; } else { ep.out16 = out16; ep.act = sh.epi; }
+      hipEvent_t a, b;
+      CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+      float best = 1e30f;
+      for (int r = 0; r < 6; ++r) {
+        ep.stamp = (r == 5) ? stamps : nullptr;
+        if (r == 5) CHK(hipMemsetAsync(stamps, 0, (size_t)max_tiles * 8 * sizeof(u64), s));
+        CHK(hipEventRecord(a, s));
+        KCHK(q3a::launch_gemm256(X, sh.K, W, sh.M, sh.N, sh.K, ep, false, s));
+        CHK(hipEventRecord(b, s));
+        CHK(hipStreamSynchronize(s));
+        float ms; CHK(hipEventElapsedTime(&ms, a, b));
+        if (r > 0 && r < 5) best = std::min(best, ms);
+      }
+      const double tf = 2.0 * sh.M * sh.N * sh.K / (best * 1e-3) * 1e-12;
+      printf("\ngemm256 %s: %d tiles (%.2f rounds of 256), %.1f us, %.0f TFLOP/s\n", sh.name, tiles, tiles / 256.0, best * 1e3, tf);
+      std::vector<u64> h((size_t)max_tiles * 8);
+      CHK(hipMemcpy(h.data(), stamps, h.size() * sizeof(u64), hipMemcpyDeviceToHost));
+      // per tile: prologue, K loop, epilogue pass 0 (stage), pass 0 (store), pass 1 (stage), pass 1 (store); rounds by start time
+      u64 t0 = ~0ull, t1 = 0;
+      for (int w = 0; w < tiles; ++w) { t0 = std::min(t0, h[w * 8]); t1 = std::max(t1, h[w * 8 + 6]); }
+      double ph[6] = {0, 0, 0, 0, 0, 0};
+      int first_round = 0;
+      double ph_first[6] = {0, 0, 0, 0, 0, 0};
+      for (int w = 0; w < tiles; ++w) {
+        const bool fr = (h[w * 8] - t0) < 200;  // started within 2 us of the launch: first round
+        first_round += fr;
+        for (int p = 0; p < 6; ++p) { const double d = (double)(h[w * 8 + p + 1] - h[w * 8 + p]) * 0.01; ph[p] += d; if (fr) ph_first[p] += d; }
+      }
+      printf("    launch span (first tile in -> last tile out, stamped run): %.1f us; tiles that started in the first 2 us: %d\n", (double)(t1 - t0) * 0.01, first_round);
+      printf("    mean per tile (all):         prologue %.2f  K-loop %.2f  stage0 %.2f  store0 %.2f  stage1 %.2f  store1 %.2f  (us; wave 0 of the tile)\n",
+             ph[0] / tiles, ph[1] / tiles, ph[2] / tiles, ph[3] / tiles, ph[4] / tiles, ph[5] / tiles);
+      if (first_round)
+        printf("    mean per tile (first round): prologue %.2f  K-loop %.2f  stage0 %.2f  store0 %.2f  stage1 %.2f  store1 %.2f\n", ph_first[0] / first_round,
+               ph_first[1] / first_round, ph_first[2] / first_round, ph_first[3] / first_round, ph_first[4] / first_round, ph_first[5] / first_round);
+    }
+  }
+  return 0;
+}
