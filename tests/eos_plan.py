@@ -30,11 +30,12 @@ def plan_ragged_eos(model_dir: str, clips: Sequence[np.ndarray], kmax: int, targ
         be decidable for a bf16 engine).
     Step 0 (empty history: the same last prompt token for everyone) is shared by the whole batch and never planned.
     Returns (stops, decidable, info): stops[u] = planted step or None, decidable[u] = number of leading steps whose greedy
-    id is decidable, info = synthetic.plant_eos's report."""
+    id is decidable at `margin_min`, info = synthetic.plant_eos's report (+ info["margins"][u] = the top-1/top-2 margin of
+    every step, for callers that compare an engine with a coarser rounding than the one the plan was made for)."""
     orc = O.AsrOracle(model_dir)
     node = {}   # token history -> "quiet" | "fire"
     plan_states, plan_fire = [], []
-    stops, decidable = [None] * len(clips), [0] * len(clips)
+    stops, decidable, all_margins = [None] * len(clips), [0] * len(clips), [None] * len(clips)
     # late stops and "never" first: they lay down quiet nodes; early stops then take what is left of the shared prefixes
     order = sorted(range(len(clips)), key=lambda u: -(kmax if targets[u] is None else int(targets[u])))
     for u in order:
@@ -58,7 +59,7 @@ def plan_ragged_eos(model_dir: str, clips: Sequence[np.ndarray], kmax: int, targ
                     if c <= lim and node.get(keys[c]) is None:
                         k = c
                         break
-        stops[u], decidable[u] = k, lim
+        stops[u], decidable[u], all_margins[u] = k, lim, margins
         for s in range(kmax if k is None else k + 1):
             fire = k is not None and s == k
             node[keys[s]] = "fire" if fire else "quiet"
@@ -67,7 +68,13 @@ def plan_ragged_eos(model_dir: str, clips: Sequence[np.ndarray], kmax: int, targ
     info = synthetic.plant_eos(model_dir, np.stack(plan_states), plan_fire)
     assert info["worst_fire"] is None or info["worst_fire"] > 8.0, info
     assert info["worst_quiet"] is None or info["worst_quiet"] < -8.0, info
+    info["margins"] = all_margins
     return stops, decidable, info
+
+
+def leading_decidable(margins: Sequence[float], margin_min: float) -> int:
+    """Number of leading steps whose top-1/top-2 margin is at least `margin_min`."""
+    return next((s for s, m in enumerate(margins) if m < margin_min), len(margins))
 
 
 def fresh_eos_checkpoint(model_dir: str, preset: str, seed: int, cfg: Optional[dict] = None, embed_scale: float = 0.5) -> str:

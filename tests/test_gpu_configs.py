@@ -26,7 +26,9 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 0.05          # default-mode max |logit error| at 0.6B / 1.7B dims (|logit| <= ~3; measured 0.012-0.022)
 EMBED_TOL = 2e-2          # rel-L2 of the audio embeddings
-MAX_UNDER_MARGIN = 0.15   # at most this fraction of the compared steps may sit inside the rounding noise (measured <= 7 %)
+MAX_UNDER_MARGIN = 0.20   # at most this fraction of the compared steps may sit inside the rounding noise (measured: <= 7 % over
+                          # 100 tokens at one clip, 9-14.5 % over 110 tokens at 32 clips -- nearly flat synthetic logits)
+MAX_FLIPS = 0.05          # fraction of steps whose greedy id may differ from the oracle's (each one justified, see margin_report)
 
 
 def rel_l2(got, ref):
@@ -47,15 +49,23 @@ def margin_report(tag, eng_tokens, eng_logits, ref, tol=None):
         worst = max(worst, err)
         top = ref.step_logits[s].topk(2).values
         margin = float(top[0] - top[1])
-        same = int(eng_tokens[s]) == int(ref.all_step_ids[s])
+        i, j = int(ref.all_step_ids[s]), int(eng_tokens[s])
+        same = i == j
         if margin > 2 * err:
-            assert same, f"{tag}: step {s}: engine {int(eng_tokens[s])} != oracle {ref.all_step_ids[s]} with margin {margin:.4f} > 2 x err {err:.4f}"
+            assert same, f"{tag}: step {s}: engine {j} != oracle {i} with margin {margin:.4f} > 2 x err {err:.4f}"
         else:
             under += 1
+        if not same:
+            # exact condition for a legitimate flip: the engine preferred j, so the oracle's gap between its own choice i
+            # and j cannot exceed the engine's errors on exactly those two logits
+            gap = float(ref_l[i] - ref_l[j])
+            pair = abs(float(eng_logits[s][i]) - float(ref_l[i])) + abs(float(eng_logits[s][j]) - float(ref_l[j]))
+            assert gap <= pair + 1e-6, f"{tag}: step {s}: flip {i} -> {j} with oracle gap {gap:.4f} > engine error on the pair {pair:.4f}"
         flips += 0 if same else 1
     print(f"[parity] {tag}: {n} steps, flips {flips}, under-margin {under} ({100.0 * under / n:.1f} %), worst |logit err| {worst:.4f}")
     assert worst <= (LOGIT_TOL if tol is None else tol), (tag, worst)
     assert under <= MAX_UNDER_MARGIN * n, f"{tag}: {under}/{n} steps under the margin -- the exact-id bound is vacuous"
+    assert flips <= max(1, MAX_FLIPS * n), f"{tag}: {flips}/{n} greedy ids differ from the oracle"
     return flips, under, worst
 
 

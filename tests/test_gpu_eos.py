@@ -15,7 +15,7 @@ from oracle import q3asr_oracle as O
 from qwen3_asr_rs_amd import _lib, synthetic
 from qwen3_asr_rs_amd.engine import HipEngine
 
-from eos_plan import fresh_eos_checkpoint, plan_ragged_eos
+from eos_plan import fresh_eos_checkpoint, leading_decidable, plan_ragged_eos
 
 pytestmark = pytest.mark.gpu
 
@@ -60,17 +60,24 @@ def test_ragged_eos_inside_a_batch_tiny_dims():
     B, kmax = 40, 9
     clips = [synthetic.synthetic_clip(200 + i, 1.0 + 0.17 * (i % 7)) for i in range(B)]
     pat = [1, None, 3, 5, 7, None, 2, 4, 8, 6, 3]
-    stops, decidable, info = plan_ragged_eos(d, clips, kmax, [pat[i % len(pat)] for i in range(B)], margin_min=0.03)
+    # planned for the precise mode (fp32-level logits: a margin of 1e-3 is decidable); the default bf16 mode is compared on
+    # the utterances whose steps in front of the stop all have a margin of 0.03 (measured logit error at these dims: 7e-3)
+    stops, decidable, info = plan_ragged_eos(d, clips, kmax, [pat[i % len(pat)] for i in range(B)], margin_min=1e-3)
+    dec_bf16 = [leading_decidable(m, 0.03) for m in info["margins"]]
     kinds = {k for k in stops}
     assert None in kinds and len(kinds) >= 5, stops
-    print(f"[eos] tiny: planted stops {stops}; EOS row norm {info['row_norm']:.1f}")
+    print(f"[eos] tiny: planted stops {stops}; EOS row norm {info['row_norm']:.1f}; bf16-decidable leading steps {dec_bf16}")
     ref = _expected(d, clips, kmax, stops)
+    runs = {}
     for precise in (True, False):
         for use_graph in (True, False):
             got, steps = _run(d, clips, kmax, precise=precise, use_graph=use_graph)
-            n = _check(f"tiny B=40 precise={precise} graph={use_graph}", got, ref, stops, decidable, exact=precise)
-            assert n >= (B if precise else B // 2), n
+            runs[precise, use_graph] = got
+            n = _check(f"tiny B=40 precise={precise} graph={use_graph}", got, ref, stops, decidable if precise else dec_bf16, exact=precise)
+            print(f"[eos] tiny B=40 precise={precise} graph={use_graph}: {n} utterances compared with the oracle")
+            assert n == B or not precise
             assert steps == kmax - 1   # a never-EOS utterance runs to the cap
+        assert runs[precise, True] == runs[precise, False], "hipGraph replay and eager launches disagree"
     # every utterance of the batch stops: the device-side all-done flag ends the loop
     fin = [u for u in range(B) if stops[u] is not None]
     try:
