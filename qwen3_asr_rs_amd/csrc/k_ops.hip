@@ -117,48 +117,54 @@ __global__ void complex_abs_kernel(float* out, const float2* in, long n) {
     out[i] = hypotf(in[i].x, in[i].y);
 }
 
-// C[b][M][N] = A[b][M][K] . B[b][K][N]  (row-major, contiguous; batch strides may be 0 = broadcast).  32 x 32 tiles,
-// fp32 FMA in the k order 0..K-1 per output (a plain dot product, like a CPU reference).
-constexpr int MT = 32;
+// C[b][M][N] = A[b][M][K] . B[b][K][N]  (row-major, contiguous; batch strides may be 0 = broadcast) on the f32-input matrix
+// core: v_mfma_f32_32x32x2_f32 is exact f32 -- D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)), one rounding per product, k ascending --
+// so every output is the same plain k-ordered fmaf chain a CPU reference (and the VALU kernel this replaces) computes, at
+// the f32 vector rate without occupying the VALU.  64 x 64 tile per workgroup, 4 waves of 32 x 32, K in steps of 32 through
+// LDS.  The tile loader is a functor so that the convolution below runs on the same body as an implicit GEMM.
+constexpr int MT = 64, MK = 32;
 // tb != 0: B is given transposed, row-major [N][K] (Linear::forward's `weight.tr()`, src/layers.rs:74-80: the weight is read in
 // place instead of being copied into a [K][N] matrix first)
+struct DenseTiles {
+  const float* a; const float* b; int M, N, K, tb;
+  __device__ __forceinline__ float A(int m, int k) const { return (m < M && k < K) ? a[(long)m * K + k] : 0.f; }
+  __device__ __forceinline__ float B(int k, int n) const { return (k < K && n < N) ? (tb ? b[(long)n * K + k] : b[(long)k * N + n]) : 0.f; }
+  __device__ __forceinline__ float init(int) const { return 0.f; }
+  __device__ __forceinline__ void store(float* c, int m, int n, float v) const { if (m < M && n < N) c[(long)m * N + n] = v; }
+};
+template <class T>
+__device__ __forceinline__ void mfma_tile_f32(const T& t, float* c, int K, bool b_k_fast) {
+  __shared__ float as[MT][MK + 1], bs[MK][MT + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * MT, n0 = blockIdx.y * MT;  // rows on x: the long dimension (implicit-GEMM convolutions)
+  f32x16_t acc;
+  {
+    const float v0 = t.init(n0 + wn * 32 + (lane & 31));  // (bias of the output column: the accumulator starts there)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = v0;
+  }
+  for (int k0 = 0; k0 < K; k0 += MK) {
+#pragma unroll
+    for (int i = 0; i < MT * MK / 256; ++i) {
+      const int idx = tid + i * 256;
+      as[idx / MK][idx % MK] = t.A(m0 + idx / MK, k0 + idx % MK);  // consecutive threads along k
+      if (b_k_fast) bs[idx % MK][idx / MK] = t.B(k0 + idx % MK, n0 + idx / MK);   // B stored [N][K]: consecutive threads along k
+      else bs[idx / MT][idx % MT] = t.B(k0 + idx / MT, n0 + idx % MT);            // B stored [K][N]: consecutive threads along n
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < MK; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[wm * 32 + (lane & 31)][kk + (lane >> 5)], bs[kk + (lane >> 5)][wn * 32 + (lane & 31)], acc, 0, 0, 0);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r)  // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    t.store(c, m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), n0 + wn * 32 + (lane & 31), acc[r]);
+}
 __global__ __launch_bounds__(256) void matmul_kernel(float* C, const float* A, const float* B, int M, int N, int K, long sa, long sb, int tb) {
-  __shared__ float as[MT][MT + 1], bs[MT][MT + 1];
   const int bz = blockIdx.z;
-  const float* a = A + (long)bz * sa;
-  const float* b = B + (long)bz * sb;
-  float* c = C + (long)bz * M * N;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 threads, 4 rows each
-  const int m0 = blockIdx.y * MT, n0 = blockIdx.x * MT;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += MT) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = ty * 4 + r;
-      const int m = m0 + row, ka = k0 + tx;
-      as[row][tx] = (m < M && ka < K) ? a[(long)m * K + ka] : 0.f;
-      if (!tb) {
-        const int kb = k0 + row, n = n0 + tx;
-        bs[row][tx] = (kb < K && n < N) ? b[(long)kb * N + n] : 0.f;
-      } else {  // coalesced along k: thread (row = n offset, tx = k offset)
-        const int n = n0 + row, kb = k0 + tx;
-        bs[tx][row] = (kb < K && n < N) ? b[(long)n * K + kb] : 0.f;
-      }
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int kk = 0; kk < MT; ++kk) {
-      const float bv = bs[kk][tx];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = fmaf(as[ty * 4 + r][kk], bv, acc[r]);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = m0 + ty * 4 + r, n = n0 + tx;
-    if (m < M && n < N) c[(long)m * N + n] = acc[r];
-  }
+  const DenseTiles t{A + (long)bz * sa, B + (long)bz * sb, M, N, K, tb};
+  mfma_tile_f32(t, C + (long)bz * M * N, K, tb != 0);
 }
 
 // one workgroup per row of D contiguous floats
@@ -269,25 +275,30 @@ __global__ void reflect_pad_kernel(float* out, const float* in, long rows, long 
   }
 }
 
-// direct NCHW convolution, groups == 1: one thread per output element
-__global__ void conv2d_kernel(float* out, const float* in, const float* w, const float* bias, ConvDims d) {
-  const long total = (long)d.N * d.Co * d.OH * d.OW;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int ow = (int)(i % d.OW), oh = (int)((i / d.OW) % d.OH), co = (int)((i / ((long)d.OW * d.OH)) % d.Co);
-    const int n = (int)(i / ((long)d.OW * d.OH * d.Co));
-    float acc = bias ? bias[co] : 0.f;
-    for (int ci = 0; ci < d.Ci; ++ci)
-      for (int kh = 0; kh < d.KH; ++kh) {
-        const int ih = oh * d.sh - d.ph + kh * d.dh;
-        if (ih < 0 || ih >= d.H) continue;
-        for (int kw = 0; kw < d.KW; ++kw) {
-          const int iw = ow * d.sw - d.pw + kw * d.dw;
-          if (iw < 0 || iw >= d.W) continue;
-          acc = fmaf(in[(((long)n * d.Ci + ci) * d.H + ih) * d.W + iw], w[(((long)co * d.Ci + ci) * d.KH + kh) * d.KW + kw], acc);
-        }
-      }
-    out[i] = acc;
+// NCHW convolution, groups == 1, as an implicit GEMM on the tile body above: row m = (image, oh, ow), column = output
+// channel, k = (ci, kh, kw) ascending -- the summation order of a direct loop nest; padded taps contribute exact zeros and
+// the accumulator starts at the bias.
+struct ConvTiles {
+  const float* in; const float* w; const float* bias; ConvDims d; int M, K;
+  __device__ __forceinline__ float A(int m, int k) const {
+    if (m >= M || k >= K) return 0.f;
+    const int ow = m % d.OW, oh = (m / d.OW) % d.OH, n = m / (d.OW * d.OH);
+    const int kw = k % d.KW, kh = (k / d.KW) % d.KH, ci = k / (d.KW * d.KH);
+    const int ih = oh * d.sh - d.ph + kh * d.dh, iw = ow * d.sw - d.pw + kw * d.dw;
+    if (ih < 0 || ih >= d.H || iw < 0 || iw >= d.W) return 0.f;
+    return in[(((long)n * d.Ci + ci) * d.H + ih) * d.W + iw];
   }
+  __device__ __forceinline__ float B(int k, int co) const { return (k < K && co < d.Co) ? w[(long)co * K + k] : 0.f; }
+  __device__ __forceinline__ float init(int co) const { return (bias && co < d.Co) ? bias[co] : 0.f; }
+  __device__ __forceinline__ void store(float* out, int m, int co, float v) const {
+    if (m >= M || co >= d.Co) return;
+    const int ow = m % d.OW, oh = (m / d.OW) % d.OH, n = m / (d.OW * d.OH);
+    out[(((long)n * d.Co + co) * d.OH + oh) * d.OW + ow] = v;
+  }
+};
+__global__ __launch_bounds__(256) void conv2d_kernel(float* out, const float* in, const float* w, const float* bias, ConvDims d) {
+  const ConvTiles t{in, w, bias, d, d.N * d.OH * d.OW, d.Ci * d.KH * d.KW};
+  mfma_tile_f32(t, out, t.K, true);
 }
 
 // STFT without centering: frame f = x[f*hop .. f*hop + n_fft) * window; out[k][f] = sum_t frame[t] * exp(-2 pi i k t / n_fft)
@@ -343,7 +354,7 @@ void k_complex_abs(float* out, const void* in, long n, hipStream_t s) {
 }
 void k_matmul(float* C, const float* A, const float* B, int batch, int M, int N, int K, long sa, long sb, bool b_transposed, hipStream_t s) {
   if (batch <= 0 || M <= 0 || N <= 0) return;
-  hipLaunchKernelGGL(matmul_kernel, dim3((N + MT - 1) / MT, (M + MT - 1) / MT, batch), dim3(256), 0, s, C, A, B, M, N, K, sa, sb, b_transposed ? 1 : 0);
+  hipLaunchKernelGGL(matmul_kernel, dim3((M + MT - 1) / MT, (N + MT - 1) / MT, batch), dim3(256), 0, s, C, A, B, M, N, K, sa, sb, b_transposed ? 1 : 0);
 }
 void k_softmax_rows(float* out, const float* in, long rows, int D, hipStream_t s) {
   if (rows <= 0) return;
@@ -373,9 +384,9 @@ void k_reflect_pad(float* out, const float* in, long rows, long n, long pl, long
   hipLaunchKernelGGL(reflect_pad_kernel, dim3(grid_for(rows * (n + pl + pr))), dim3(256), 0, s, out, in, rows, n, pl, pr);
 }
 void k_conv2d(float* out, const float* in, const float* w, const float* bias, const ConvDims& d, hipStream_t s) {
-  const long total = (long)d.N * d.Co * d.OH * d.OW;
-  if (total <= 0) return;
-  hipLaunchKernelGGL(conv2d_kernel, dim3(grid_for(total)), dim3(256), 0, s, out, in, w, bias, d);
+  const long rows = (long)d.N * d.OH * d.OW;
+  if (rows <= 0 || d.Co <= 0) return;
+  hipLaunchKernelGGL(conv2d_kernel, dim3((unsigned)((rows + MT - 1) / MT), (d.Co + MT - 1) / MT), dim3(256), 0, s, out, in, w, bias, d);
 }
 void k_stft(void* out, const float* x, const float* win, const float* ct, const float* st, int n_fft, int hop, int n_frames,
             int n_freq, float scale, hipStream_t s) {
