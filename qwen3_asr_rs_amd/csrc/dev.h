@@ -13,6 +13,13 @@
 #define Q3A_STAMP_AT(ptr, wg, slot) do { } while (0)
 #endif
 
+// hipcc loads kernel arguments lazily -- a scalar load right in front of each first use -- and on this chip a scalar load
+// that misses (the kernarg segment of a fresh dispatch always does) is a 0.3-0.5 us round trip: the stamped timelines of
+// tools/phase_probe.hip showed 1.4-2.2 us between a kernel's entry and its last load request, most of it three or four
+// such round trips in series.  Q3A_ARG(x) makes x (a kernel-argument expression) resident in SGPRs at that point; a
+// block of them at the top of a kernel turns the series into ONE clause that overlaps the address arithmetic.
+#define Q3A_ARG(x) asm volatile("" ::"s"(x))
+
 namespace q3a {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;  // MFMA 16x16x32 bf16 A/B operand (4 VGPRs)

@@ -73,6 +73,12 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
   __shared__ __attribute__((aligned(16))) KVT v_s[128];
   __shared__ float cm[DA_WAVES][GROUP], cl[DA_WAVES][GROUP];
   __shared__ float co[DA_WAVES][GROUP][128];
+  // pos in front of the Q3A_ARG block: behind it (asm volatile) hipcc no longer proves the location clobber-free and turns
+  // the scalar load into a vector load that it waits for at once
+  const int pos = a.pos[s];
+  // every argument in one scalar-load clause (dev.h Q3A_ARG) instead of three scalar round trips in series
+  Q3A_ARG(a.qkv); Q3A_ARG(a.pos); Q3A_ARG(a.q_norm); Q3A_ARG(a.k_norm); Q3A_ARG(a.eps); Q3A_ARG(a.rope_cur); Q3A_ARG(a.kcache); Q3A_ARG(a.vcache);
+  Q3A_ARG(a.pm); Q3A_ARG(a.pl); Q3A_ARG(a.po); Q3A_ARG(a.nsplit); Q3A_ARG(a.n_q); Q3A_ARG(a.n_kv); Q3A_ARG(a.max_ctx); Q3A_ARG(a.scale_div);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPK, kq = lane / LPK;
   const int key_lo = sp * KEYS_PER_SPLIT;
@@ -123,7 +129,6 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     load_rows();
   }
   __builtin_amdgcn_sched_barrier(0);
-  const int pos = a.pos[s];
   if (key_lo > pos) {  // this split holds no key yet: statistics of an empty set, zeroed output
     if (tid < GROUP) { a.pm[pbase + (size_t)tid * a.nsplit] = -INFINITY; a.pl[pbase + (size_t)tid * a.nsplit] = 0.f; }
     if (tid < GROUP * 128) a.po[(pbase + (size_t)(tid >> 7) * a.nsplit) * 128 + (tid & 127)] = 0.f;
@@ -415,6 +420,11 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   __shared__ __attribute__((aligned(16))) KVT v_s[128];
   __shared__ float cm[DA_WAVES][GROUP], cl[DA_WAVES][GROUP];
   __shared__ float co[DA_WAVES][GROUP][128];
+  const int pos = a.pos[blockIdx.y];  // (a scalar load as long as it sits in front of the Q3A_ARG block: see decode_attn_body)
+  // every argument in one scalar-load clause (dev.h Q3A_ARG): the prologue had three scalar round trips in series in front
+  // of the first cache-row request
+  Q3A_ARG(a.qkv); Q3A_ARG(a.pos); Q3A_ARG(a.q_norm); Q3A_ARG(a.k_norm); Q3A_ARG(a.eps); Q3A_ARG(a.rope_cur); Q3A_ARG(a.kcache); Q3A_ARG(a.vcache);
+  Q3A_ARG(a.n_q); Q3A_ARG(a.n_kv); Q3A_ARG(a.max_ctx); Q3A_ARG(a.scale_div); Q3A_ARG(a.out); Q3A_ARG(a.out16); Q3A_ARG(a.out_frag);
   const int kvh = blockIdx.x, s = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int stamp_wg = blockIdx.y * gridDim.x + blockIdx.x;
@@ -459,7 +469,6 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   if constexpr (RING > 3) load_tile(3, kr3, vr3);
   __builtin_amdgcn_sched_barrier(0);
   Q3A_STAMP_AT(a.stamp, stamp_wg, 1);  // q/k/v row + first tiles requested
-  const int pos = a.pos[s];
   const int n_tiles = pos / TILE + 1;  // tiles that hold at least one key <= pos
 
   if (wave <= GROUP) {  // per-head RMSNorm + RoPE (as dev.h head_norm_rope)

@@ -75,6 +75,15 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];  // WLDS: [wave][tile][UNR/2 columns][16 rows][128 B]
   __shared__ float part[SK_WAVES][TILES][SH][16][17];  // [k-slice][tile][seq half][row][sequence] (+1 pad)
   __shared__ float ssp[SK_WAVES][SH][16];              // XMODE 1: sum(x^2) of each sequence over the wave's K slice
+  // every argument this instantiation touches, in one scalar-load clause (dev.h Q3A_ARG)
+  Q3A_ARG(a.W); Q3A_ARG(a.N); Q3A_ARG(a.K); Q3A_ARG(a.S); Q3A_ARG(a.ldx); Q3A_ARG(a.bias); Q3A_ARG(a.mode); Q3A_ARG(a.out); Q3A_ARG(a.ldo);
+  Q3A_ARG(a.resid); Q3A_ARG(a.eps);
+  if (XMODE <= 1) { Q3A_ARG(a.x); Q3A_ARG(a.rms_w); }
+  if (XMODE == 2) { Q3A_ARG(a.x16); Q3A_ARG(a.x16_frag); }
+  if (XMODE == 3) { Q3A_ARG(a.xw16f); Q3A_ARG(a.ss_parts); Q3A_ARG(a.ss_nparts); }
+  if (TILES == 2) { Q3A_ARG(a.out16); Q3A_ARG(a.out16_frag); }
+  if (TILES == 1) { Q3A_ARG(a.next_w); Q3A_ARG(a.next_xw16f); Q3A_ARG(a.next_ss); }
+  if (QS) Q3A_ARG(a.qs_halves);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   Q3A_STAMP_AT(a.stamp, blockIdx.x, 0);  // entry
   const int l15 = lane & 15, kc = lane >> 4;  // row / sequence inside the fragment, k-chunk (8 elements)
@@ -125,22 +134,26 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   const int ep_i = QS ? (tid & 7) : (tid & 15), ep_s = QS ? hsel * 16 + ((tid >> 3) & 15) : (tid >> 4);
   const bool ep_live = QS ? (tid < 128 && ep_s < a.S) : (ep_s < a.S && (SH == 2 || ep_s < 16));
   float ep_resid = 0.f, ep_bias = 0.f, ep_nw = 0.f;
-  if (TILES == 1 && ep_live && n0 + ep_i < a.N) {
-    if (a.mode == 1) ep_resid = a.resid[(size_t)ep_s * a.ldo + n0 + ep_i];
-    if (a.bias) ep_bias = a.bias[n0 + ep_i];
-    if (a.mode == 1 && a.next_w) ep_nw = a.next_w[n0 + ep_i];
+  if (TILES == 1) {  // clamped addresses, no lane-divergent branch around the loads (the epilogue only uses them where live)
+    const int en = min(n0 + ep_i, a.N - 1), es = min(ep_s, a.S - 1);
+    if (a.mode == 1) ep_resid = a.resid[(size_t)es * a.ldo + en];
+    if (a.bias) ep_bias = a.bias[en];
+    if (a.mode == 1 && a.next_w) ep_nw = a.next_w[en];
   }
   // XMODE 3: this lane's share of the producer's sum(x^2) partial rows (p = wave*4 + kc, then every 32nd): the first SS_PRE
   // of them are requested here, in front of the weight stream, so their L2 round trip is not on the tail of the kernel
-  constexpr int SS_PRE = 4;  // covers 128 partial rows (hidden 1024 in 8-column blocks)
+  constexpr int SS_PRE = 8;  // covers 256 partial rows (hidden 2048 in 8-column blocks); anything beyond is summed after the K loop
   float ssq[SH][SS_PRE];
   if (XMODE == 3) {
 #pragma unroll
     for (int h = 0; h < SH; ++h)
 #pragma unroll
       for (int j = 0; j < SS_PRE; ++j) {
-        const int p = wave * 4 + kc + j * SK_WAVES * 4;
-        ssq[h][j] = p < a.ss_nparts ? a.ss_parts[(size_t)p * 32 + (QS ? hsel : h) * 16 + l15] : 0.f;
+        // unconditional (clamped) load, selected afterwards: with `p < n ? load : 0` hipcc puts every load into its own
+        // exec-masked block and waits vmcnt(0) between them -- two L2 round trips in series in front of the weight stream
+        const int p = wave * 4 + kc + j * SK_WAVES * 4, pc = min(p, a.ss_nparts - 1);
+        const float v = a.ss_parts[(size_t)pc * 32 + (QS ? hsel : h) * 16 + l15];
+        ssq[h][j] = p < a.ss_nparts ? v : 0.f;
       }
   }
   unsigned char* const wbase = wlds + (size_t)wave * (TILES * (UNR / 2) * PIECES * 1024);
