@@ -307,6 +307,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
   // C/D layout (col = lane & 15, row = (lane >> 4) * 4 + reg) ----
   float* stg = reinterpret_cast<float*>(lds + wave * 16384);  // [64][64] fp32
   const int col_in = lane & 15, row_in = (lane >> 4) * 4;
+  const bool wide16 = (N % 8 == 0) && (ep.ldo % 8 == 0);  // bf16 rows that can be written 16 B per lane (kernel-uniform)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -377,6 +378,46 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
         }
       }
       __syncthreads();  // the partner is done with this wave's staged half before the next pass overwrites it
+    } else if (!GLU && ep.out16 && wide16) {
+      // bf16 output, 8 columns per lane: ONE 16-B store per lane and iteration (8 rows x 128 B per wave instruction).  The
+      // stamped timeline (profiles/r3_phase_probe_start.txt) had this phase at 4.7 us per 64-row pass with 8-B stores --
+      // 13 GB/s per CU, store-issue bound -- next to 17 us of K loop at K = 896.
+      const int c8 = (lane & 7) * 8, n = n0 + wc * 64 + c8;
+      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+      if (ep.bias && n < N) { b0 = *reinterpret_cast<const float4*>(ep.bias + n); b1 = *reinterpret_cast<const float4*>(ep.bias + n + 4); }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), m = mrow0 + row;
+        float4 v0 = *reinterpret_cast<const float4*>(&stg[row * 64 + c8]);
+        float4 v1 = *reinterpret_cast<const float4*>(&stg[row * 64 + c8 + 4]);
+        if (m >= M || n >= N) continue;
+        const int orow = ep.rowmap ? ep.rowmap[m] : m;
+        if (orow < 0) continue;
+        v0.x += b0.x; v0.y += b0.y; v0.z += b0.z; v0.w += b0.w;
+        v1.x += b1.x; v1.y += b1.y; v1.z += b1.z; v1.w += b1.w;
+        if (ep.addend) {
+          const float* ad = ep.addend + (size_t)(m % ep.addend_period) * ep.ldo + n;
+          const float4 a0 = *reinterpret_cast<const float4*>(ad), a1 = *reinterpret_cast<const float4*>(ad + 4);
+          v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w;
+          v1.x += a1.x; v1.y += a1.y; v1.z += a1.z; v1.w += a1.w;
+        }
+        if (ep.act == 1) {  // packed: every multiply / fma of the polynomial serves two values
+          const f32x2_t g0 = gelu_fast2(f32x2_t{v0.x, v0.y}), g1 = gelu_fast2(f32x2_t{v0.z, v0.w});
+          const f32x2_t g2 = gelu_fast2(f32x2_t{v1.x, v1.y}), g3 = gelu_fast2(f32x2_t{v1.z, v1.w});
+          v0 = make_float4(g0.x, g0.y, g1.x, g1.y);
+          v1 = make_float4(g2.x, g2.y, g3.x, g3.y);
+        }
+        if (ep.resid) {
+          const float* rs = ep.resid + (size_t)orow * ep.ldo + n;
+          const float4 r0 = *reinterpret_cast<const float4*>(rs), r1 = *reinterpret_cast<const float4*>(rs + 4);
+          v0.x += r0.x; v0.y += r0.y; v0.z += r0.z; v0.w += r0.w;
+          v1.x += r1.x; v1.y += r1.y; v1.z += r1.z; v1.w += r1.w;
+        }
+        uint4 pk;
+        pk.x = pack_bf16x2(v0.x, v0.y); pk.y = pack_bf16x2(v0.z, v0.w);
+        pk.z = pack_bf16x2(v1.x, v1.y); pk.w = pack_bf16x2(v1.z, v1.w);
+        *reinterpret_cast<uint4*>(ep.out16 + (size_t)orow * ep.ldo + n) = pk;
+      }
     } else if (!GLU) {
       const int c4 = (lane & 15) * 4, n = n0 + wc * 64 + c4;
 #pragma unroll 4
@@ -407,6 +448,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
         } else {
           *reinterpret_cast<float4*>(ep.out + (size_t)orow * ep.ldo + n) = v;
         }
+      }
+    } else if (ep.out16 && wide16) {
+      // GLU, bf16 output, 8 output columns per lane (one 16-B store): W rows are [16 gate | 16 up] blocks, so the staged
+      // columns [0,16) / [16,32) are gate / up of output columns 0..15 and [32,64) likewise
+      const int oc8 = (lane & 3) * 8, gc = (oc8 >> 4) * 32 + (oc8 & 15);
+      const int nb = n0 + wc * 64 + gc;            // W row of the first gate value
+      const int on = ((n0 + wc * 64) >> 1) + oc8;  // output column
+      float4 bg0 = make_float4(0.f, 0.f, 0.f, 0.f), bg1 = bg0, bu0 = bg0, bu1 = bg0;
+      if (ep.bias && nb + 16 < N) {
+        bg0 = *reinterpret_cast<const float4*>(ep.bias + nb); bg1 = *reinterpret_cast<const float4*>(ep.bias + nb + 4);
+        bu0 = *reinterpret_cast<const float4*>(ep.bias + nb + 16); bu1 = *reinterpret_cast<const float4*>(ep.bias + nb + 20);
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 16 + (lane >> 2), m = mrow0 + row;
+        float4 g0 = *reinterpret_cast<const float4*>(&stg[row * 64 + gc]), g1 = *reinterpret_cast<const float4*>(&stg[row * 64 + gc + 4]);
+        float4 u0 = *reinterpret_cast<const float4*>(&stg[row * 64 + gc + 16]), u1 = *reinterpret_cast<const float4*>(&stg[row * 64 + gc + 20]);
+        if (m >= M || nb + 16 >= N) continue;
+        const int orow = ep.rowmap ? ep.rowmap[m] : m;
+        if (orow < 0) continue;
+        g0.x += bg0.x; g0.y += bg0.y; g0.z += bg0.z; g0.w += bg0.w; g1.x += bg1.x; g1.y += bg1.y; g1.z += bg1.z; g1.w += bg1.w;
+        u0.x += bu0.x; u0.y += bu0.y; u0.z += bu0.z; u0.w += bu0.w; u1.x += bu1.x; u1.y += bu1.y; u1.z += bu1.z; u1.w += bu1.w;
+        uint4 pk;
+        pk.x = pack_bf16x2(silu_fast(g0.x) * u0.x, silu_fast(g0.y) * u0.y); pk.y = pack_bf16x2(silu_fast(g0.z) * u0.z, silu_fast(g0.w) * u0.w);
+        pk.z = pack_bf16x2(silu_fast(g1.x) * u1.x, silu_fast(g1.y) * u1.y); pk.w = pack_bf16x2(silu_fast(g1.z) * u1.z, silu_fast(g1.w) * u1.w);
+        *reinterpret_cast<uint4*>(ep.out16 + (size_t)orow * ep.ldo + on) = pk;
       }
     } else {
       // W rows are [16 gate | 16 up] blocks: staged columns [0,16) gate / [16,32) up of output columns 0..15, [32,64) likewise
