@@ -12,6 +12,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle's greedy steps are GEMV-bound: on the GPU boxes' 128-thread hosts PyTorch runs them faster on 16 threads
+    # than on all of them (bench.py's cpu_baseline probe: 98 ms/token on 16), and the GPU suite spends most of its time there.
+    try:
+        import torch
+        if (os.cpu_count() or 1) > 32:
+            torch.set_num_threads(16)
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
