@@ -526,11 +526,11 @@ struct q3a_engine {
     }
     total_P = off;
     max_new = std::min(std::max(max_new_req, 1), opts.max_new_tokens);
-    max_ctx = ((maxP + max_new + 1 + 63) / 64) * 64;
+    max_ctx = ((maxP + max_new + 1 + 127) / 128) * 128;  // whole 128-key tiles (the batched decode attention reads cache rows tile by tile)
     {  // A/B knob: extra keys per (sequence, kv head) cache row block, so that the streams of the batched decode attention
        // do not all start a power of two apart (512 keys x 256 B = 128 KiB)
       static const int pad = [] { const char* e = getenv("Q3A_CTX_PAD"); return e ? atoi(e) : 0; }();
-      if (pad > 0) max_ctx += (pad + 7) / 8 * 8;
+      if (pad > 0) max_ctx += (pad + 127) / 128 * 128;
     }
     ensure_rope(max_ctx + 1);  // argmax_finalize reads the row of the position AFTER the last one the cache can hold
     std::vector<int> ids_v(ids_h, ids_h + total_P);

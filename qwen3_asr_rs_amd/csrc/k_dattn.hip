@@ -435,6 +435,31 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   KVT* kc = reinterpret_cast<KVT*>(a.kcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
   KVT* vc = reinterpret_cast<KVT*>(a.vcache) + ((size_t)s * a.n_kv + kvh) * (size_t)a.max_ctx * 128;
 
+  const int key_w = wave * KEYS_PER_WAVE + kq;  // this lane's first key inside a tile
+  // Register ring of RING tiles: the rows of tiles t+1 .. t+RING-1 are in flight while tile t is consumed (one CU must
+  // keep > 100 KB requested to stream its share of HBM bandwidth; with one tile ahead the loop ran at one memory round
+  // trip per 128 keys: 15.3 us per layer at 32 sequences x 500 keys against ~10 us of HBM time)
+  constexpr int RING = DOT2 ? RING_T : 1;  // (the fp32 cache of the precise mode has twice the registers per tile: no ring there)
+  static_assert(RING >= 1 && RING <= 4 && NI >= 1, "ring depth / tile size");
+  uint4 kr0[NI], vr0[NI], kr1[RING > 1 ? NI : 1], vr1[RING > 1 ? NI : 1], kr2[RING > 2 ? NI : 1], vr2[RING > 2 ? NI : 1], kr3[RING > 3 ? NI : 1], vr3[RING > 3 ? NI : 1];
+  // The cache rows go FIRST (stamped timeline: 2.2 us passed between the entry and the last request of the first two tiles
+  // with the new token's rows in front -- the memory pipe of a kernel that is bound by its 256 KB per CU sat idle that long).
+  // max_ctx is a multiple of TILE (launcher), so only the TILE index is clamped (scalar): one base address per tile, the
+  // NI rows of a lane are KPI * 256 B apart (immediate offsets).  Rows beyond pos hold stale data and are masked below.
+  const int last_tile = a.max_ctx / TILE - 1;
+  const size_t lane_off = (size_t)key_w * 128 + sub * DPL;
+  auto load_tile = [&](int t, uint4 (&kr)[NI], uint4 (&vr)[NI]) {
+    const size_t base = (size_t)min(t, last_tile) * (TILE * 128) + lane_off;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      kr[i] = ld_stream16(kc + base + (size_t)i * (KPI * 128));
+      vr[i] = ld_stream16(vc + base + (size_t)i * (KPI * 128));
+    }
+  };
+  load_tile(0, kr0, vr0);
+  // the new token's q / k / v rows, norm weights and RoPE row go BETWEEN tile 0 and the rest of the ring: loads return in
+  // order, so they are back right behind tile 0 -- when they are first needed -- and tile 0 is consumed (and the ring
+  // refilled) while tile 1 is still in flight
   float x1 = 0.f, x2 = 0.f, nw1 = 0.f, nw2 = 0.f, c = 0.f, sn = 0.f;
   if (wave < GROUP + 2) {  // waves 0..GROUP-1: the q heads, GROUP: k, GROUP+1: v
     const int r = wave < GROUP ? kvh * GROUP + wave : (wave == GROUP ? a.n_q + kvh : a.n_q + a.n_kv + kvh);
@@ -448,22 +473,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
       sn = a.rope_cur[(size_t)s * 128 + 64 + lane];
     }
   }
-  const int key_w = wave * KEYS_PER_WAVE + kq;  // this lane's first key inside a tile
-  // Register ring of RING tiles: the rows of tiles t+1 .. t+RING-1 are in flight while tile t is consumed (one CU must
-  // keep > 100 KB requested to stream its share of HBM bandwidth; with one tile ahead the loop ran at one memory round
-  // trip per 128 keys: 15.3 us per layer at 32 sequences x 500 keys against ~10 us of HBM time)
-  constexpr int RING = DOT2 ? RING_T : 1;  // (the fp32 cache of the precise mode has twice the registers per tile: no ring there)
-  static_assert(RING >= 1 && RING <= 4 && NI >= 1, "ring depth / tile size");
-  uint4 kr0[NI], vr0[NI], kr1[RING > 1 ? NI : 1], vr1[RING > 1 ? NI : 1], kr2[RING > 2 ? NI : 1], vr2[RING > 2 ? NI : 1], kr3[RING > 3 ? NI : 1], vr3[RING > 3 ? NI : 1];
-  auto load_tile = [&](int t, uint4 (&kr)[NI], uint4 (&vr)[NI]) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int key = min(t * TILE + key_w + i * KPI, a.max_ctx - 1);  // stale / clamped rows are masked below
-      kr[i] = ld_stream16(kc + (size_t)key * 128 + sub * DPL);
-      vr[i] = ld_stream16(vc + (size_t)key * 128 + sub * DPL);
-    }
-  };
-  load_tile(0, kr0, vr0);
+  __builtin_amdgcn_sched_barrier(0);  // (keeps the row requests in front of the following tiles)
   if constexpr (RING > 1) load_tile(1, kr1, vr1);  // unconditional (clamped): nothing here waits for `pos`
   if constexpr (RING > 2) load_tile(2, kr2, vr2);
   if constexpr (RING > 3) load_tile(3, kr3, vr3);
@@ -722,6 +732,7 @@ const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f
   if (S <= 0) return nullptr;
   if (!a.out && !a.out16) return "decode_attn_batched: no output buffer";
   if (a.out16 && a.out_frag && S > 32) return "decode_attn_batched: fragment order holds at most 32 sequences";
+  if (a.max_ctx % 128 != 0) return "decode_attn_batched: max_ctx must be a multiple of 128 (whole key tiles)";
   const int group = a.n_q / a.n_kv;
   dim3 grid(a.n_kv, S), block(DA_WAVES * 64);
   // A/B knob Q3A_DATTN_TILE64=1: 64-key tiles with a 4-deep register ring (same bytes in flight, steadier request stream)

@@ -325,56 +325,93 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
       // DPP, and q leaves as bf16 [rows][n_q * 128], k / v go to their cache rows (src/layers.rs:303-319,361-375) --
       // the fp32 qkv matrix (16 KiB per token at 0.6B) is never written or re-read.
       __syncthreads();
+      // 8 columns per lane: 8 lanes per row, 8 rows per iteration, ONE 16-B store per lane and iteration; the row's position
+      // (and sequence) are requested for all 8 iterations up front so that the cos / sin rows -- whose address depends on
+      // them -- are not a second dependent round trip inside every iteration
       const float* pst = reinterpret_cast<const float*>(lds + (wave ^ 1) * 16384);
-      const int c4 = (lane & 15) * 4;
+      const int c8 = (lane & 7) * 8;
       const int ncol = n0 + wc * 64;               // first W row of this wave's columns
       const int hv = ncol >> 7;                    // head vector index: q heads, then k heads, then v heads
       const bool second = (wc & 1) != 0;           // this wave holds dims 64..127 of the head
-      const int d_own = (second ? 64 : 0) + c4, d_par = (second ? 0 : 64) + c4;
+      const int d_own = (second ? 64 : 0) + c8, d_par = (second ? 0 : 64) + c8;
       const bool is_q = hv < rk.n_q, is_k = !is_q && hv < rk.n_q + rk.n_kv;
       const float* nw = is_q ? rk.q_norm : rk.k_norm;
-      float4 w_own = make_float4(1.f, 1.f, 1.f, 1.f), w_par = w_own;
+      float w_own[8], w_par[8], b_own[8], b_par[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { w_own[e] = 1.f; w_par[e] = 1.f; b_own[e] = 0.f; b_par[e] = 0.f; }
       if (is_q || is_k) {
-        w_own = *reinterpret_cast<const float4*>(nw + d_own);
-        w_par = *reinterpret_cast<const float4*>(nw + d_par);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const float4 a = *reinterpret_cast<const float4*>(nw + d_own + h2 * 4), c = *reinterpret_cast<const float4*>(nw + d_par + h2 * 4);
+          w_own[h2 * 4] = a.x; w_own[h2 * 4 + 1] = a.y; w_own[h2 * 4 + 2] = a.z; w_own[h2 * 4 + 3] = a.w;
+          w_par[h2 * 4] = c.x; w_par[h2 * 4 + 1] = c.y; w_par[h2 * 4 + 2] = c.z; w_par[h2 * 4 + 3] = c.w;
+        }
       }
-      float4 b_own = make_float4(0.f, 0.f, 0.f, 0.f), b_par = b_own;
       if (ep.bias && ncol < N) {
-        b_own = *reinterpret_cast<const float4*>(ep.bias + (hv << 7) + d_own);
-        b_par = *reinterpret_cast<const float4*>(ep.bias + (hv << 7) + d_par);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const float4 a = *reinterpret_cast<const float4*>(ep.bias + (hv << 7) + d_own + h2 * 4);
+          const float4 c = *reinterpret_cast<const float4*>(ep.bias + (hv << 7) + d_par + h2 * 4);
+          b_own[h2 * 4] = a.x; b_own[h2 * 4 + 1] = a.y; b_own[h2 * 4 + 2] = a.z; b_own[h2 * 4 + 3] = a.w;
+          b_par[h2 * 4] = c.x; b_par[h2 * 4 + 1] = c.y; b_par[h2 * 4 + 2] = c.z; b_par[h2 * 4 + 3] = c.w;
+        }
       }
-#pragma unroll 4
-      for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + (lane >> 4), m = mrow0 + row;
-        const int mc = m < M ? m : M - 1;
-        float4 xo = *reinterpret_cast<const float4*>(&stg[row * 64 + c4]);
-        float4 xp = *reinterpret_cast<const float4*>(&pst[row * 64 + c4]);
-        const int pos = rk.row_pos[mc];
-        xo.x += b_own.x; xo.y += b_own.y; xo.z += b_own.z; xo.w += b_own.w;
-        xp.x += b_par.x; xp.y += b_par.y; xp.z += b_par.z; xp.w += b_par.w;
-        float4 v = xo;
+      int posv[8], seqv[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int m = mrow0 + it * 8 + (lane >> 3), mc = m < M ? m : M - 1;
+        posv[it] = rk.row_pos[mc];
+        seqv[it] = is_q ? 0 : rk.row_seq[mc];
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), m = mrow0 + row;
+        const int pos = posv[it];
+        float xo[8], xp[8];
+        {
+          const float4 o0 = *reinterpret_cast<const float4*>(&stg[row * 64 + c8]), o1 = *reinterpret_cast<const float4*>(&stg[row * 64 + c8 + 4]);
+          const float4 p0 = *reinterpret_cast<const float4*>(&pst[row * 64 + c8]), p1 = *reinterpret_cast<const float4*>(&pst[row * 64 + c8 + 4]);
+          xo[0] = o0.x; xo[1] = o0.y; xo[2] = o0.z; xo[3] = o0.w; xo[4] = o1.x; xo[5] = o1.y; xo[6] = o1.z; xo[7] = o1.w;
+          xp[0] = p0.x; xp[1] = p0.y; xp[2] = p0.z; xp[3] = p0.w; xp[4] = p1.x; xp[5] = p1.y; xp[6] = p1.z; xp[7] = p1.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xo[e] += b_own[e]; xp[e] += b_par[e]; }
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = xo[e];
         if (is_q || is_k) {  // wave-uniform
-          const float4 cs = *reinterpret_cast<const float4*>(rk.cos_t + (size_t)pos * 64 + c4);
-          const float4 sn = *reinterpret_cast<const float4*>(rk.sin_t + (size_t)pos * 64 + c4);
-          float ss = xo.x * xo.x + xo.y * xo.y + xo.z * xo.z + xo.w * xo.w + xp.x * xp.x + xp.y * xp.y + xp.z * xp.z + xp.w * xp.w;
-          ss = row16_sum(ss);
+          float cs[8], sn[8];
+          {
+            const float* cp = rk.cos_t + (size_t)pos * 64 + c8;
+            const float* sp = rk.sin_t + (size_t)pos * 64 + c8;
+            const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
+            const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+            cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
+            sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+          }
+          float ss = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss += xo[e] * xo[e] + xp[e] * xp[e];
+          ss = row8_sum(ss);  // the 8 lanes of this row hold all 128 dims between them
           const float rstd = 1.0f / sqrtf(ss / 128.0f + rk.eps);
-          const float4 no = make_float4((xo.x * rstd) * w_own.x, (xo.y * rstd) * w_own.y, (xo.z * rstd) * w_own.z, (xo.w * rstd) * w_own.w);
-          float4 np = make_float4((xp.x * rstd) * w_par.x, (xp.y * rstd) * w_par.y, (xp.z * rstd) * w_par.z, (xp.w * rstd) * w_par.w);
-          if (!second) { np.x = -np.x; np.y = -np.y; np.z = -np.z; np.w = -np.w; }  // rotate_half = cat(-x2, x1)
-          v = make_float4(no.x * cs.x + np.x * sn.x, no.y * cs.y + np.y * sn.y, no.z * cs.z + np.z * sn.z, no.w * cs.w + np.w * sn.w);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float no = (xo[e] * rstd) * w_own[e];
+            float np = (xp[e] * rstd) * w_par[e];
+            if (!second) np = -np;  // rotate_half = cat(-x2, x1)
+            v[e] = no * cs[e] + np * sn[e];
+          }
         }
         if (m >= M || ncol >= N) continue;
-        uint2 pk;
-        pk.x = pack_bf16x2(v.x, v.y);
-        pk.y = pack_bf16x2(v.z, v.w);
+        uint4 pk;
+        pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
         if (is_q) {
-          *reinterpret_cast<uint2*>(rk.q16 + (size_t)m * rk.n_q * 128 + (size_t)hv * 128 + d_own) = pk;
+          *reinterpret_cast<uint4*>(rk.q16 + (size_t)m * rk.n_q * 128 + (size_t)hv * 128 + d_own) = pk;
         } else {
           const int kvh = is_k ? hv - rk.n_q : hv - rk.n_q - rk.n_kv;
           uint16_t* c = reinterpret_cast<uint16_t*>(is_k ? rk.kcache : rk.vcache) +
-                        (((size_t)rk.row_seq[mc] * rk.n_kv + kvh) * rk.max_ctx + pos) * 128 + d_own;
-          *reinterpret_cast<uint2*>(c) = pk;
+                        (((size_t)seqv[it] * rk.n_kv + kvh) * rk.max_ctx + pos) * 128 + d_own;
+          *reinterpret_cast<uint4*>(c) = pk;
         }
       }
       __syncthreads();  // the partner is done with this wave's staged half before the next pass overwrites it

@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
 
   if (do_layer) {
     // ---------------- part 1: the batched decode layer ----------------
-    const int S = 32, H = 1024, I = 3072, NQ = 16, NKV = 8, QD = NQ * 128, QKV = (NQ + 2 * NKV) * 128, MAXCTX = 576, POS = 500;
+    const int S = 32, H = 1024, I = 3072, NQ = 16, NKV = 8, QD = NQ * 128, QKV = (NQ + 2 * NKV) * 128, MAXCTX = 640, POS = 500;
     const int L = 28, STEPS = 6;
     // per-layer slab in the pool: qkv_w, o_w, gu_w, down_w, K cache, V cache
     const size_t e_qkv = (size_t)QKV * H, e_o = (size_t)H * QD, e_gu = (size_t)2 * I * H, e_dn = (size_t)H * I, e_kv = (size_t)S * NKV * MAXCTX * 128;
