@@ -80,6 +80,8 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
   Q3A_ARG(a.qkv); Q3A_ARG(a.pos); Q3A_ARG(a.q_norm); Q3A_ARG(a.k_norm); Q3A_ARG(a.eps); Q3A_ARG(a.rope_cur); Q3A_ARG(a.kcache); Q3A_ARG(a.vcache);
   Q3A_ARG(a.pm); Q3A_ARG(a.pl); Q3A_ARG(a.po); Q3A_ARG(a.nsplit); Q3A_ARG(a.n_q); Q3A_ARG(a.n_kv); Q3A_ARG(a.max_ctx); Q3A_ARG(a.scale_div);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int stamp_wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  Q3A_STAMP_AT(a.stamp, stamp_wg, 0);  // entry
   const int sub = lane % LPK, kq = lane / LPK;
   const int key_lo = sp * KEYS_PER_SPLIT;
   const size_t pbase = ((size_t)s * a.n_q + (size_t)kvh * GROUP) * a.nsplit + sp;  // + g * nsplit
@@ -129,6 +131,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     load_rows();
   }
   __builtin_amdgcn_sched_barrier(0);
+  Q3A_STAMP_AT(a.stamp, stamp_wg, 1);  // every load requested
   if (key_lo > pos) {  // this split holds no key yet: statistics of an empty set, zeroed output
     if (tid < GROUP) { a.pm[pbase + (size_t)tid * a.nsplit] = -INFINITY; a.pl[pbase + (size_t)tid * a.nsplit] = 0.f; }
     if (tid < GROUP * 128) a.po[(pbase + (size_t)(tid >> 7) * a.nsplit) * 128 + (tid & 127)] = 0.f;
@@ -159,6 +162,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     KvIo<KVT>::store(&v_s[lane + 64], x2);
   }
   __syncthreads();
+  Q3A_STAMP_AT(a.stamp, stamp_wg, 2);  // q (and the new k / v) in LDS
 
   // ---- scores for this wave's 16 keys ----
   // This section is VALU work on the critical path (a wave64 VALU instruction occupies its SIMD for 4 cycles and two
@@ -220,6 +224,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
       for (int e = 0; e < DPL / 2; ++e) acc[g][e] += f32x2_t{p, p} * f32x2_t{vf[2 * e], vf[2 * e + 1]};
     }
   }
+  Q3A_STAMP_AT(a.stamp, stamp_wg, 3);  // scores + P.V of wave 0's keys (its cache rows have landed)
   // fold the KPI key columns of the wave (lanes with equal `sub`)
 #pragma unroll
   for (int g = 0; g < GROUP; ++g) {
@@ -239,6 +244,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     }
   }
   __syncthreads();
+  Q3A_STAMP_AT(a.stamp, stamp_wg, 4);  // wave partials in LDS
   // ---- merge the 8 waves, write the split's partial ----
   if (wave < GROUP) {
     const int g = wave;
@@ -258,6 +264,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     a.po[pi * 128 + lane] = o0;
     a.po[pi * 128 + lane + 64] = o1;
   }
+  Q3A_STAMP_AT(a.stamp, stamp_wg, 5);
 }
 
 template <int GROUP, typename KVT>

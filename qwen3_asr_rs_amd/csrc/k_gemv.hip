@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   __shared__ int am_i[4][1];
   __shared__ __attribute__((aligned(16))) float x_s[ATTN ? KI * 512 : 4];  // only the attention merge goes through LDS
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  Q3A_STAMP_AT(a.stamp, blockIdx.x, 0);  // entry
   const int K = a.K;
   // (an XCD-contiguous block -> row remap, so that each output line is dirtied in one L2 only, measured 0.6 % slower)
   const int g = blockIdx.x * 4 + wave;
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
     rv[i] = a.mode == 1 ? a.resid[n] : 0.f;
   }
   __builtin_amdgcn_sched_barrier(0);  // every request is issued before anything is waited for
+  Q3A_STAMP_AT(a.stamp, blockIdx.x, 1);  // every load requested
   if (ATTN) {  // each wave merges a quarter of the vector, once per block
 #pragma unroll
     for (int it = 0; it < KI; ++it) {
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
       xr[it][1] = *reinterpret_cast<const float4*>(x_s + kk[it] + 4);
     }
   }
+  Q3A_STAMP_AT(a.stamp, blockIdx.x, 2);  // (ATTN: merged vector in LDS)
   float x[KI][8];
   float ss = 0.f;  // (packing sum(x^2) and x * w_norm two wide measured 0.6 % slower on the whole step)
 #pragma unroll
@@ -328,6 +331,8 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   for (int it = 0; it < KI; ++it)
 #pragma unroll
     for (int i = 0; i < PR; ++i) acc[i][0] = dot8(wq[it][i], x[it], acc[i][0]);
+  if (wave == 0) asm volatile("" ::"v"(acc[0][0]));  // (the stamp below sits behind the FMAs of wave 0, i.e. behind its weights)
+  Q3A_STAMP_AT(a.stamp, blockIdx.x, 3);  // weights landed, dot products done
   float rstd = 1.0f;
   if (RMS) rstd = 1.0f / sqrtf(wave_sum_fast(ss) / (float)K + a.eps);  // a wave covers all of K
 #pragma unroll
@@ -364,6 +369,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
     for (int i = 0; i + 1 < PR; i += 2)
       if (prow[i] >= 0) a.out[g * (PR / 2) + (i >> 1)] = silu_f(acc[i][0]) * acc[i + 1][0];
   }
+  Q3A_STAMP_AT(a.stamp, blockIdx.x, 4);  // reduced and stored
 }
 
 // ---- NB in {2, 4}: x staged through LDS once per workgroup ---------------------------------------------

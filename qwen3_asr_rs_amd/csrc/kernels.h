@@ -166,6 +166,7 @@ struct GemvArgs {
   // (x/ldx ignored; K must equal attn_heads*128)
   const float* attn_pm; const float* attn_pl; const float* attn_po; int attn_nsplit; int attn_heads;
   int attn_fast_exp;            // merge weights with the hardware exponential (default mode) instead of expf
+  Q3A_STAMP_FIELD
 };
 const char* launch_gemv(const GemvArgs& a, int NB, hipStream_t s);
 constexpr int GEMV_ATTN_MAX_TABLE = 1024;  // min(NB,4) * heads * nsplit must fit (else merge with launch_attn_combine first)

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "k_dattn.hip"
+#include "k_gemv.hip"
 #include "k_gemm16.hip"
 #include "k_gemm256.hip"
 #include "k_skinny.hip"
@@ -54,17 +55,22 @@ static void summarize(const char* title, const std::vector<const char*>& kind_na
     const int np = (int)phase_names[l.kind].size();  // stamps 0 .. np
     u64 s0min = ~0ull, s0max = 0, endmax = 0;
     std::vector<double> sum(8, 0);
+    int live = 0;
     for (int w = 0; w < l.wgs; ++w) {
       const u64* r = &st[(l.off + w) * 8];
-      s0min = std::min(s0min, r[0]); s0max = std::max(s0max, r[0]); endmax = std::max(endmax, r[np]);
+      s0min = std::min(s0min, r[0]); s0max = std::max(s0max, r[0]);
+      if (r[np] == 0) { endmax = std::max(endmax, r[1] ? r[1] : r[0]); continue; }  // a workgroup that left early (empty key split)
+      ++live;
+      endmax = std::max(endmax, r[np]);
       for (int p = 0; p < np; ++p) sum[p] += (double)(r[p + 1] - r[p]);
     }
+    if (!live) live = 1;
     if ((int)li >= skip_first) {
       cnt[l.kind]++;
       if (prev_end) gap[l.kind] += (double)((long long)s0min - (long long)prev_end) * tick_us;
       ramp[l.kind] += (double)(s0max - s0min) * tick_us;
       span[l.kind] += (double)(endmax - s0min) * tick_us;
-      for (int p = 0; p < np; ++p) ph[l.kind][p] += sum[p] / l.wgs * tick_us;
+      for (int p = 0; p < np; ++p) ph[l.kind][p] += sum[p] / live * tick_us;
     }
     prev_end = endmax;
   }
@@ -79,11 +85,11 @@ static void summarize(const char* title, const std::vector<const char*>& kind_na
 }
 
 int main(int argc, char** argv) {
-  const bool do_layer = argc < 2 || strstr(argv[1], "layer"), do_gemm = argc < 2 || strstr(argv[1], "gemm");
+  const bool do_layer = argc < 2 || strstr(argv[1], "layer"), do_gemm = argc < 2 || strstr(argv[1], "gemm"), do_one = argc < 2 || strstr(argv[1], "one");
   hipStream_t s;
   CHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   KCHK(q3a::skinny_init());
-  const size_t WB = (size_t)12 << 29;  // 6 GiB pool (bf16 elements' worth of pool (elements, not bytes, below): weights and KV of 56 successive layers walk through it
+  const size_t WB = (size_t)14 << 29;  // 7 GiB pool (bf16 elements' worth of pool (elements, not bytes, below): weights and KV of 56 successive layers walk through it
   uint16_t* pool;
   CHK(hipMalloc(&pool, WB));
   CHK(hipMemset(pool, 0x3c, WB));  // bf16 0x3c3c = 0.0115: finite everywhere
@@ -176,6 +182,89 @@ int main(int argc, char** argv) {
                   {{"issue", "wait", "mfma", "to-lds+barrier", "reduce+store"}, {"issue", "qkv-row+barrier", "tiles", "fold+barrier", "merge+store"},
                    {"issue", "wait", "mfma", "to-lds+barrier", "reduce+store"}, {"issue", "wait", "mfma", "to-lds+barrier", "reduce+store"},
                    {"issue", "wait", "mfma", "to-lds+barrier", "reduce+store"}},
+                  ls, h, 5 * L);
+      }
+    }
+  }
+
+
+  if (do_one) {
+    // ---------------- part 3: the one-sequence decode layer (bench default: GEMV path) ----------------
+    const int H = 1024, I = 3072, NQ = 16, NKV = 8, QD = NQ * 128, QKV = (NQ + 2 * NKV) * 128, MAXCTX = 640, POS = 455, NSPLIT = 5;
+    const int L = 28, STEPS = 8;
+    const size_t e_qkv = (size_t)QKV * H, e_o = (size_t)H * QD, e_gu = (size_t)2 * I * H, e_dn = (size_t)H * I, e_kv = (size_t)NKV * MAXCTX * 128;
+    const size_t slab = e_qkv + e_o + e_gu + e_dn + 2 * e_kv;
+    if (slab * L * 2 > pool_elems) { printf("pool too small\n"); return 1; }
+    float *x, *qkv, *rope, *nw, *act, *pm, *pl, *po;
+    int* pos;
+    CHK(hipMalloc(&x, H * 4)); CHK(hipMalloc(&qkv, QKV * 4)); CHK(hipMalloc(&rope, 128 * 4)); CHK(hipMalloc(&nw, 8192 * 4)); CHK(hipMalloc(&act, I * 4));
+    CHK(hipMalloc(&pm, NQ * NSPLIT * 4)); CHK(hipMalloc(&pl, NQ * NSPLIT * 4)); CHK(hipMalloc(&po, (size_t)NQ * NSPLIT * 128 * 4)); CHK(hipMalloc(&pos, 4));
+    CHK(hipMemset(x, 0, H * 4)); CHK(hipMemset(qkv, 0, QKV * 4)); CHK(hipMemset(act, 0, I * 4));
+    {
+      std::vector<float> ones(8192, 1.0f), rc(128);
+      for (int i = 0; i < 128; ++i) rc[i] = i < 64 ? 1.0f : 0.0f;
+      const int p = POS;
+      CHK(hipMemcpy(nw, ones.data(), 8192 * 4, hipMemcpyHostToDevice)); CHK(hipMemcpy(rope, rc.data(), 128 * 4, hipMemcpyHostToDevice));
+      CHK(hipMemcpy(pos, &p, 4, hipMemcpyHostToDevice));
+    }
+    auto blocks = [&](int N, int K, int mode) { q3a::GemvArgs g{}; g.N = N; g.K = K; g.mode = mode; return q3a::gemv_blocks(g); };
+    const int wg_qkv = blocks(QKV, H, 0), wg_att = NKV * NSPLIT, wg_o = blocks(H, QD, 1), wg_gu = blocks(2 * I, H, 2), wg_dn = blocks(H, I, 1);
+    const int per_layer = wg_qkv + wg_att + wg_o + wg_gu + wg_dn;
+    const size_t rows = (size_t)per_layer * L * STEPS;
+    u64* stamps;
+    CHK(hipMalloc(&stamps, rows * 8 * sizeof(u64)));
+    CHK(hipMemset(stamps, 0, rows * 8 * sizeof(u64)));
+    std::vector<Launch> ls;
+    auto layer = [&](int idx, bool record, bool stamped) {
+      uint16_t* base = pool + (size_t)(idx % (2 * L)) * slab;
+      const uint16_t *w_qkv = base, *w_o = w_qkv + e_qkv, *w_gu = w_o + e_o, *w_dn = w_gu + e_gu;
+      uint16_t *kc = const_cast<uint16_t*>(w_dn) + e_dn, *vc = kc + e_kv;
+      size_t off = (size_t)idx * per_layer;
+      auto rec = [&](int kind, int wgs) -> u64* { u64* p = stamped ? stamps + off * 8 : nullptr; if (record) ls.push_back({kind, wgs, off}); off += wgs; return p; };
+      q3a::GemvArgs g{};
+      g.x = x; g.ldx = H; g.rms_w = nw; g.eps = 1e-6f; g.W = w_qkv; g.N = QKV; g.K = H; g.mode = 0; g.out = qkv; g.ldo = QKV; g.stamp = rec(0, wg_qkv);
+      KCHK(q3a::launch_gemv(g, 1, s));
+      q3a::DecodeAttnArgs da{};
+      da.qkv = qkv; da.pos = pos; da.eps = 1e-6f; da.rope_cur = rope; da.q_norm = nw; da.k_norm = nw; da.kcache = kc; da.vcache = vc;
+      da.pm = pm; da.pl = pl; da.po = po; da.nsplit = NSPLIT; da.n_q = NQ; da.n_kv = NKV; da.max_ctx = MAXCTX; da.scale_div = 11.3137f; da.stamp = rec(1, wg_att);
+      KCHK(q3a::launch_decode_attn(da, 1, false, s));
+      q3a::GemvArgs o{};
+      o.attn_pm = pm; o.attn_pl = pl; o.attn_po = po; o.attn_nsplit = NSPLIT; o.attn_heads = NQ; o.attn_fast_exp = 1;
+      o.ldx = QD; o.W = w_o; o.N = H; o.K = QD; o.mode = 1; o.out = x; o.ldo = H; o.resid = x; o.stamp = rec(2, wg_o);
+      KCHK(q3a::launch_gemv(o, 1, s));
+      q3a::GemvArgs u{};
+      u.x = x; u.ldx = H; u.rms_w = nw; u.eps = 1e-6f; u.W = w_gu; u.N = 2 * I; u.K = H; u.mode = 2; u.out = act; u.ldo = I; u.stamp = rec(3, wg_gu);
+      KCHK(q3a::launch_gemv(u, 1, s));
+      q3a::GemvArgs d{};
+      d.x = act; d.ldx = I; d.W = w_dn; d.N = H; d.K = I; d.mode = 1; d.out = x; d.ldo = H; d.resid = x; d.stamp = rec(4, wg_dn);
+      KCHK(q3a::launch_gemv(d, 1, s));
+    };
+    for (int stamped = 1; stamped >= 0; --stamped) {
+      hipGraph_t g;
+      hipGraphExec_t ge;
+      CHK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+      for (int i = 0; i < L * STEPS; ++i) layer(i, stamped == 1, stamped == 1);
+      CHK(hipStreamEndCapture(s, &g));
+      CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      hipEvent_t a, b;
+      CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+      CHK(hipGraphLaunch(ge, s));
+      CHK(hipStreamSynchronize(s));
+      float best = 1e30f;
+      for (int r = 0; r < 4; ++r) {
+        CHK(hipEventRecord(a, s)); CHK(hipGraphLaunch(ge, s)); CHK(hipEventRecord(b, s)); CHK(hipStreamSynchronize(s));
+        float ms; CHK(hipEventElapsedTime(&ms, a, b)); best = std::min(best, ms);
+      }
+      printf("\none-sequence decode layer (%d keys, 0.6B dims), %s: %.2f us per layer (%.1f us per 28-layer step without lm_head)\n", POS + 1,
+             stamped ? "stamps on" : "stamps off (null pointer)", best * 1e3 / (L * STEPS), best * 1e3 / STEPS);
+      CHK(hipGraphExecDestroy(ge)); CHK(hipGraphDestroy(g));
+      if (stamped) {
+        std::vector<u64> h(rows * 8);
+        CHK(hipMemcpy(h.data(), stamps, h.size() * sizeof(u64), hipMemcpyDeviceToHost));
+        summarize("phases of the one-sequence decode layer (last replay)",
+                  {"gemv qkv (rms)", "decode_attn (8 heads x 5 splits)", "gemv o (split merge)", "gemv gate/up (rms, GLU)", "gemv down"},
+                  {{"issue", "(merge)", "weights+fma", "reduce+store"}, {"issue", "rows+barrier", "scores+pv", "fold+barrier", "merge+store"},
+                   {"issue", "(merge)", "weights+fma", "reduce+store"}, {"issue", "(merge)", "weights+fma", "reduce+store"}, {"issue", "(merge)", "weights+fma", "reduce+store"}},
                   ls, h, 5 * L);
       }
     }

@@ -1,5 +1,7 @@
 """Per-kernel averages of every counter in one or more rocprofv3 `--pmc` databases (rocpd SQLite, *_results.db):
-    python tools/pmc_kernels.py OUT1/x_results.db [OUT2/y_results.db ...] [--match substring]
+    python tools/pmc_kernels.py OUT1/x_results.db [OUT2/y_results.db ...] [--match substring] [--by-grid]
+--by-grid keeps dispatches of one kernel with different grid sizes apart (a GEMM kernel serves several shapes: the grid
+size names the shape, e.g. 539 x 512 threads = the encoder qkv projection at 32 clips).
 Counters are summed over the dimensions rocprofv3 reports (XCD / SE / ...), averaged over the dispatches of a kernel.
 Derived lines: SQ shares of SQ_WAVE_CYCLES, LDS bank-conflict rate, MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES /
 (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs) when both are present (MI355X_MICROARCH.md, rocprofv3 PMC slots)."""
@@ -16,6 +18,8 @@ def short(n):
 
 def main(argv):
     match = None
+    by_grid = "--by-grid" in argv
+    argv = [a for a in argv if a != "--by-grid"]
     if "--match" in argv:
         i = argv.index("--match")
         match = argv[i + 1]
@@ -24,11 +28,12 @@ def main(argv):
     for path in argv:
         db = sqlite3.connect(path)
         # one row per (dispatch, counter, dimension instance): sum the instances of a dispatch, then average over dispatches
-        rows = db.execute("select kernel_name, counter_name, dispatch_id, sum(value) from counters_collection "
-                          "group by kernel_name, counter_name, dispatch_id").fetchall()
+        rows = db.execute("select kernel_name, counter_name, dispatch_id, sum(value), max(grid_size), max(workgroup_size) "
+                          "from counters_collection group by kernel_name, counter_name, dispatch_id").fetchall()
         acc = defaultdict(list)
-        for k, c, _, v in rows:
-            acc[(short(k), c)].append(v)
+        for k, c, _, v, gs, ws in rows:
+            name = short(k) + (f"  [grid {int(gs) // max(int(ws), 1)} workgroups]" if by_grid else "")
+            acc[(name, c)].append(v)
         for (k, c), vs in acc.items():
             data[k][c] = (sum(vs) / len(vs), len(vs))
     for k in sorted(data, key=lambda k: -data[k].get("SQ_WAVE_CYCLES", data[k].get("GRBM_GUI_ACTIVE", (0, 0)))[0]):
