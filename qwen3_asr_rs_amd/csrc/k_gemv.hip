@@ -99,8 +99,8 @@ __device__ __forceinline__ void attn_combined8(const GemvArgs& a, int b, int k, 
 // statistics themselves (same-address loads, one request) together with the partial outputs -- every load is
 // independent, one L2 round trip -- and rescale online over chunks of 4 splits.
 // FAST: hardware exponential (default mode); the precise mode keeps expf.
-template <bool FAST>
-__device__ __forceinline__ void attn_merge8(const GemvArgs& a, int b, int k, float (&x)[8]) {
+template <bool FAST, int CH>
+__device__ __forceinline__ void attn_merge8_ch(const GemvArgs& a, int b, int k, float (&x)[8]) {
   auto ex = [](float v) { return FAST ? __expf(v) : expf(v); };
   const int h = k >> 7, d = k & 127;
   const int ns = a.attn_nsplit;
@@ -108,11 +108,14 @@ __device__ __forceinline__ void attn_merge8(const GemvArgs& a, int b, int k, flo
   float M = -INFINITY, L = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) x[e] = 0.f;
-  for (int sp0 = 0; sp0 < ns; sp0 += 4) {
-    float m[4], l[4];
-    float4 o0[4], o1[4];
+  // Chunks of CH splits: every load of a chunk is requested before anything is combined.  CH = 4 up to 512 keys, 8 beyond:
+  // contexts up to 1024 keys cost ONE L2 round trip (with chunks of 4 the fifth split of a 513..640-key context was a
+  // second one: 2.4 us of merge in this kernel, profiles/r3_phase_probe_decode_layers.txt).
+  for (int sp0 = 0; sp0 < ns; sp0 += CH) {
+    float m[CH], l[CH];
+    float4 o0[CH], o1[CH];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < CH; ++j) {
       const int sp = sp0 + j, spc = sp < ns ? sp : ns - 1;  // clamp the address, void the statistics
       m[j] = a.attn_pm[base + spc];
       l[j] = a.attn_pl[base + spc];
@@ -120,16 +123,18 @@ __device__ __forceinline__ void attn_merge8(const GemvArgs& a, int b, int k, flo
       o0[j] = *reinterpret_cast<const float4*>(a.attn_po + (size_t)(base + spc) * 128 + d);
       o1[j] = *reinterpret_cast<const float4*>(a.attn_po + (size_t)(base + spc) * 128 + d + 4);
     }
-    const float Mn = fmaxf(fmaxf(M, fmaxf(m[0], m[1])), fmaxf(m[2], m[3]));
+    float Mn = M;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) Mn = fmaxf(Mn, m[j]);
     if (Mn == -INFINITY) continue;  // only empty splits so far
-    if (sp0 > 0) {  // rescale what the earlier chunks accumulated (nothing in the common <= 4-split case)
+    if (sp0 > 0) {  // rescale what the earlier chunks accumulated (nothing in the common <= 8-split case)
       const float sc = (M == -INFINITY) ? 0.f : ex(M - Mn);
       L *= sc;
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] *= sc;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < CH; ++j) {
       const float f = ex(m[j] - Mn);  // empty split: exp(-inf) = 0 (Mn is finite here)
       L += l[j] * f;
       x[0] += o0[j].x * f; x[1] += o0[j].y * f; x[2] += o0[j].z * f; x[3] += o0[j].w * f;
@@ -140,6 +145,11 @@ __device__ __forceinline__ void attn_merge8(const GemvArgs& a, int b, int k, flo
   const float inv = 1.0f / L;  // split 0 always holds at least the current token
 #pragma unroll
   for (int e = 0; e < 8; ++e) x[e] *= inv;
+}
+template <bool FAST>
+__device__ __forceinline__ void attn_merge8(const GemvArgs& a, int b, int k, float (&x)[8]) {
+  if (a.attn_nsplit <= 4) attn_merge8_ch<FAST, 4>(a, b, k, x);  // kernel-argument condition: uniform
+  else attn_merge8_ch<FAST, 8>(a, b, k, x);
 }
 
 template <int PR>
