@@ -64,7 +64,8 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
   constexpr int DPL = Frag16<KVT>::DPL;   // head dims per lane: 8 (bf16) / 4 (f32)
   constexpr int LPK = 128 / DPL;          // lanes per key: 16 / 32
   constexpr int KPI = 64 / LPK;           // keys per load instruction: 4 / 2
-  constexpr int NI = (128 / DA_WAVES) / KPI;  // load instructions per wave: 4 / 8 at 16 keys per wave
+  constexpr int SPLIT_KEYS = sizeof(KVT) == 2 ? DATTN_KEYS_PER_SPLIT_BF16 : DATTN_KEYS_PER_SPLIT_F32;
+  constexpr int NI = (SPLIT_KEYS / DA_WAVES) / KPI;  // load instructions per wave: 4 / 8 at 16 keys per wave
   constexpr int KEYS_PER_WAVE = KPI * NI;     // 16 with 8 waves
   constexpr int KEYS_PER_SPLIT = KEYS_PER_WAVE * DA_WAVES;  // 128
   static_assert(KEYS_PER_SPLIT == (sizeof(KVT) == 2 ? DATTN_KEYS_PER_SPLIT_BF16 : DATTN_KEYS_PER_SPLIT_F32), "split size");

@@ -237,7 +237,10 @@ struct DecodeAttnArgs {
   int out_frag;
   Q3A_STAMP_FIELD
 };
-constexpr int DATTN_KEYS_PER_SPLIT_BF16 = 128, DATTN_KEYS_PER_SPLIT_F32 = 128;
+#ifndef Q3A_DATTN_SPLIT_KEYS
+#define Q3A_DATTN_SPLIT_KEYS 128  // keys per flash-decoding split of the one-sequence path (A/B builds: 64)
+#endif
+constexpr int DATTN_KEYS_PER_SPLIT_BF16 = Q3A_DATTN_SPLIT_KEYS, DATTN_KEYS_PER_SPLIT_F32 = 128;
 inline int dattn_keys_per_split(bool kv_f32) { return kv_f32 ? DATTN_KEYS_PER_SPLIT_F32 : DATTN_KEYS_PER_SPLIT_BF16; }
 const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
 // ONE sequence, 8 kv heads x 2 query heads: the qkv projection (RMSNorm fused, as the GEMV) and the attention splits in one
