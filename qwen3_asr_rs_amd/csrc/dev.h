@@ -137,8 +137,17 @@ __device__ __forceinline__ f32x2_t gelu_fast2(f32x2_t x) {
   return f32x2_t{hx.x * (x.x >= 0.f ? 2.0f - pe.x : pe.x), hx.y * (x.y >= 0.f ? 2.0f - pe.y : pe.y)};
 }
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// 1 / sqrt(v) for the RMSNorm scale of the decode-step kernels in the default mode: one v_rsq_f32 (1 ulp) instead of
+// sqrt + an IEEE division (~20 dependent instructions on the tail of a 4 us kernel); the precise mode keeps 1 / sqrtf.
+#ifndef Q3A_FAST_EPILOGUE
+#define Q3A_FAST_EPILOGUE 1  // A/B builds: 0 restores the exact forms everywhere
+#endif
+__device__ __forceinline__ float rstd_of(float mean_sq_plus_eps, bool fast) {
+  return (Q3A_FAST_EPILOGUE && fast) ? __builtin_amdgcn_rsqf(mean_sq_plus_eps) : 1.0f / sqrtf(mean_sq_plus_eps);
+}
 // SiLU (reference: Tensor::silu, src/tensor.rs:354-356)
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_sel(float x, bool fast) { return (Q3A_FAST_EPILOGUE && fast) ? silu_fast(x) : silu_f(x); }
 
 __device__ __forceinline__ float lane_bcast(float v, int lane_uniform) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));

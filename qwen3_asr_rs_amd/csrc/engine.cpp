@@ -594,6 +594,7 @@ struct q3a_engine {
     int n_part = 0;
     if (S <= kGemvMaxSeq) {
       GemvArgs g{};
+      g.fast_math = precise() ? 0 : 1;
       g.x = x_dec.as<float>(); g.ldx = H; g.rms_w = wf(L.final_norm); g.eps = d.rms_eps;
       g.W = wh(L.lm_head); g.N = V; g.K = H; g.mode = 3; g.out = logits.as<float>(); g.ldo = V;
       g.part_val = part_val.as<float>(); g.part_idx = part_idx.as<int>(); g.part_stride = part_stride;
@@ -726,6 +727,7 @@ struct q3a_engine {
     const int S = B;  // (precise-mode lm_head only)
     if (S <= 32) {
       SkinnyArgs sk{};
+      sk.fast_math = precise() ? 0 : 1;
       sk.x = x; sk.ldx = ldx; sk.S = S; sk.W = W; sk.N = N; sk.K = K; sk.bias = bias; sk.mode = mode; sk.out = out; sk.ldo = ldo; sk.resid = resid;
       KCHK(launch_skinny(sk, precise(), stream));
     } else {
@@ -754,6 +756,7 @@ struct q3a_engine {
     da.kcache = (uint8_t*)kc_layer(li) + (size_t)s0 * kv_seq; da.vcache = (uint8_t*)vc_layer(li) + (size_t)s0 * kv_seq;
     if (gemv) {
       GemvArgs g{};
+      g.fast_math = precise() ? 0 : 1;
       g.x = x; g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
       g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = qkv; g.ldo = QKV;
       if (k_fuse_qkv_attn != 0 && S == 1 && d.n_kv == 8 && d.n_q == 16 && (H == 1024 || H == 2048) && attn_nsplit <= 32) {
@@ -768,6 +771,7 @@ struct q3a_engine {
         timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
       }
       GemvArgs o{};
+      o.fast_math = precise() ? 0 : 1;
       if (std::min(S, 4) * d.n_q * attn_nsplit <= GEMV_ATTN_MAX_TABLE) {  // merge the key splits inside the o_proj GEMV
         o.attn_pm = da.pm; o.attn_pl = da.pl; o.attn_po = da.po;
         o.attn_nsplit = attn_nsplit; o.attn_heads = d.n_q; o.attn_fast_exp = precise() ? 0 : 1;
@@ -779,10 +783,12 @@ struct q3a_engine {
       o.mode = 1; o.out = x; o.ldo = H; o.resid = x;
       timed(Q3A_KC_GEMV_O, 2.0 * H * QD, [&] { KCHK(launch_gemv(o, S, ks)); });
       GemvArgs u{};
+      u.fast_math = precise() ? 0 : 1;
       u.x = x; u.ldx = H; u.rms_w = wf(l.post_ln); u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
       u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act_g(grp); u.ldo = I;
       timed(Q3A_KC_GEMV, 4.0 * I * H, [&] { KCHK(launch_gemv(u, S, ks)); });
       GemvArgs dn{};
+      dn.fast_math = precise() ? 0 : 1;
       dn.x = s_act_g(grp); dn.ldx = I; dn.W = wh(l.down_w); dn.N = H; dn.K = I; dn.bias = mlp_bias ? wf(l.down_b) : nullptr;
       dn.mode = 1; dn.out = x; dn.ldo = H; dn.resid = x;
       timed(Q3A_KC_GEMV_DOWN, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, ks)); });
@@ -792,6 +798,7 @@ struct q3a_engine {
     // bf16 activations written by their producers (attention, SwiGLU epilogue) in fragment order
     const bool b16 = !precise(), pre = prenorm_path();
     SkinnyArgs q{};
+    q.fast_math = precise() ? 0 : 1;
     q.x = x; q.ldx = H; q.S = S; q.eps = d.rms_eps; q.W = wh(l.qkv_w); q.N = QKV; q.K = H;
     if (pre) { q.xw16f = nn_x_g(grp); q.ss_parts = nn_ss_g(grp); q.ss_nparts = nn_parts(); }
     else q.rms_w = wf(l.in_ln);
@@ -806,18 +813,21 @@ struct q3a_engine {
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, attn_nsplit, S, d.n_q, s_ctx_g(grp), ks, b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr, b16)); });
     }
     SkinnyArgs o{};
+    o.fast_math = precise() ? 0 : 1;
     o.x = s_ctx_g(grp); o.x16 = b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr; o.x16_frag = b16; o.ldx = QD; o.S = S; o.W = wh(l.o_w); o.N = H; o.K = QD;
     o.bias = o_bias ? wf(l.o_b) : nullptr; o.mode = 1; o.out = x; o.ldo = H; o.resid = x;
     if (pre) { o.next_w = wf(l.post_ln); o.next_xw16f = nn_x_g(grp); o.next_ss = nn_ss_g(grp); }
     o.qsplit = b16 && skinny_q();
     timed(Q3A_KC_GEMM, 2.0 * H * QD, [&] { KCHK(launch_skinny(o, precise(), ks)); });
     SkinnyArgs u{};
+    u.fast_math = precise() ? 0 : 1;
     u.x = x; u.ldx = H; u.S = S; u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
     if (pre) { u.xw16f = nn_x_g(grp); u.ss_parts = nn_ss_g(grp); u.ss_nparts = nn_parts(); }
     else u.rms_w = wf(l.post_ln);
     u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act_g(grp); u.out16 = b16 ? reinterpret_cast<uint16_t*>(s_act_g(grp)) : nullptr; u.out16_frag = b16; u.ldo = I;
     timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_skinny(u, precise(), ks)); });
     SkinnyArgs dn{};
+    dn.fast_math = precise() ? 0 : 1;
     dn.x = s_act_g(grp); dn.x16 = b16 ? reinterpret_cast<uint16_t*>(s_act_g(grp)) : nullptr; dn.x16_frag = b16; dn.ldx = I; dn.S = S; dn.W = wh(l.down_w); dn.N = H; dn.K = I;
     dn.bias = mlp_bias ? wf(l.down_b) : nullptr; dn.mode = 1; dn.out = x; dn.ldo = H; dn.resid = x;
     dn.qsplit = b16 && skinny_q();
@@ -1329,10 +1339,12 @@ int32_t q3a_profile_weight_stream(q3a_engine* e, int32_t reps, float* avg_us, do
     for (int li = 0; li < d.dec_layers; ++li) {
       const DecLayerOff& l = e->L.dec[li];
       GemvArgs g{};
+      g.fast_math = e->precise() ? 0 : 1;
       g.x = e->x_dec.as<float>(); g.ldx = H; g.rms_w = e->wf(l.in_ln); g.eps = d.rms_eps; g.W = e->wh(l.qkv_w); g.N = QKV; g.K = H;
       g.mode = 0; g.out = e->s_qkv.as<float>(); g.ldo = QKV;
       KCHK(launch_gemv(g, S, e->stream));
       GemvArgs u{};
+      u.fast_math = e->precise() ? 0 : 1;
       u.x = e->x_dec.as<float>(); u.ldx = H; u.rms_w = e->wf(l.post_ln); u.eps = d.rms_eps; u.W = e->wh(l.gu_w); u.N = 2 * I; u.K = H;
       u.mode = 2; u.out = e->s_act.as<float>(); u.ldo = I;
       KCHK(launch_gemv(u, S, e->stream));

@@ -143,7 +143,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
   // ---- new token: q for the GROUP heads of this kv head; k/v only in the owning split ----
   if (wave <= GROUP) {  // per-head RMSNorm + RoPE (as dev.h head_norm_rope)
     const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
-    const float rstd = 1.0f / sqrtf(ss / 128.0f + a.eps);
+    const float rstd = rstd_of(ss / 128.0f + a.eps, sizeof(KVT) == 2);  // bf16 cache = default mode: hardware rsq
     const float n1 = (x1 * rstd) * nw1, n2 = (x2 * rstd) * nw2;
     x1 = n1 * c + (-n2) * sn;  // rotate_half = cat(-x2, x1)
     x2 = n2 * c + n1 * sn;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
 
   if (wave <= GROUP) {  // per-head RMSNorm + RoPE (as dev.h head_norm_rope)
     const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
-    const float rstd = 1.0f / sqrtf(ss / 128.0f + a.eps);
+    const float rstd = rstd_of(ss / 128.0f + a.eps, sizeof(KVT) == 2);  // bf16 cache = default mode: hardware rsq
     const float n1 = (x1 * rstd) * nw1, n2 = (x2 * rstd) * nw2;
     x1 = n1 * c + (-n2) * sn;
     x2 = n2 * c + n1 * sn;

@@ -234,7 +234,7 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int g, const in
       for (int b = 0; b < NB; ++b) {
         float gv = acc[i][b], uv = acc[i + 1][b];
         if (a.bias) { gv += a.bias[prow[i]]; uv += a.bias[prow[i + 1]]; }
-        a.out[(size_t)b * a.ldo + j] = silu_f(gv) * uv;
+        a.out[(size_t)b * a.ldo + j] = silu_sel(gv, a.fast_math != 0) * uv;
       }
     }
   }
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   if (wave == 0) asm volatile("" ::"v"(acc[0][0]));  // (the stamp below sits behind the FMAs of wave 0, i.e. behind its weights)
   Q3A_STAMP_AT(a.stamp, blockIdx.x, 3);  // weights landed, dot products done
   float rstd = 1.0f;
-  if (RMS) rstd = 1.0f / sqrtf(wave_sum_fast(ss) / (float)K + a.eps);  // a wave covers all of K
+  if (RMS) rstd = rstd_of(wave_sum_fast(ss) / (float)K + a.eps, a.fast_math != 0);  // a wave covers all of K
 #pragma unroll
   for (int i = 0; i < PR; ++i) acc[i][0] = wave_sum_fast(acc[i][0]) * rstd + bv[i];
   // epilogue (bias already added; acc is valid on every lane)
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   } else {
 #pragma unroll
     for (int i = 0; i + 1 < PR; i += 2)
-      if (prow[i] >= 0) a.out[g * (PR / 2) + (i >> 1)] = silu_f(acc[i][0]) * acc[i + 1][0];
+      if (prow[i] >= 0) a.out[g * (PR / 2) + (i >> 1)] = silu_sel(acc[i][0], a.fast_math != 0) * acc[i + 1][0];
   }
   Q3A_STAMP_AT(a.stamp, blockIdx.x, 4);  // reduced and stored
 }
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void gemvn_kernel(GemvArgs a) {
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     float rstd = 1.0f;
-    if (a.rms_w) rstd = 1.0f / sqrtf((red[b][0] + red[b][1] + red[b][2] + red[b][3]) / (float)K + a.eps);
+    if (a.rms_w) rstd = rstd_of((red[b][0] + red[b][1] + red[b][2] + red[b][3]) / (float)K + a.eps, a.fast_math != 0);
 #pragma unroll
     for (int i = 0; i < PR; ++i) acc[i][b] = wave_sum_fast(acc[i][b]) * rstd;
   }

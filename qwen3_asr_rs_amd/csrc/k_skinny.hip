@@ -77,7 +77,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   __shared__ float ssp[SK_WAVES][SH][16];              // XMODE 1: sum(x^2) of each sequence over the wave's K slice
   // every argument this instantiation touches, in one scalar-load clause (dev.h Q3A_ARG)
   Q3A_ARG(a.W); Q3A_ARG(a.N); Q3A_ARG(a.K); Q3A_ARG(a.S); Q3A_ARG(a.ldx); Q3A_ARG(a.bias); Q3A_ARG(a.mode); Q3A_ARG(a.out); Q3A_ARG(a.ldo);
-  Q3A_ARG(a.resid); Q3A_ARG(a.eps);
+  Q3A_ARG(a.resid); Q3A_ARG(a.eps); Q3A_ARG(a.fast_math);
   if (XMODE <= 1) { Q3A_ARG(a.x); Q3A_ARG(a.rms_w); }
   if (XMODE == 2) { Q3A_ARG(a.x16); Q3A_ARG(a.x16_frag); }
   if (XMODE == 3) { Q3A_ARG(a.xw16f); Q3A_ARG(a.ss_parts); Q3A_ARG(a.ss_nparts); }
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     float q = 0.f;
 #pragma unroll
     for (int w = 0; w < SK_WAVES; ++w) q += ssp[w][sh][sj];
-    const float rstd = 1.0f / sqrtf(q / (float)K + a.eps);
+    const float rstd = rstd_of(q / (float)K + a.eps, a.fast_math != 0);
 #pragma unroll
     for (int t = 0; t < TILES; ++t) v[t] *= rstd;
   }
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     if (!live_s || n0 + 16 + i >= a.N) return;
     float g = v[0], u = v[TILES - 1];
     if (a.bias) { g += a.bias[n0 + i]; u += a.bias[n0 + 16 + i]; }
-    const float y = silu_f(g) * u;
+    const float y = silu_sel(g, a.fast_math != 0) * u;
     if (a.out16) a.out16[a.out16_frag ? skinny_frag_index(s, (n0 >> 1) + i) : (size_t)s * a.ldo + (n0 >> 1) + i] = (uint16_t)f32_to_bf16_bits(y);
     else a.out[(size_t)s * a.ldo + (n0 >> 1) + i] = y;
     Q3A_STAMP_AT(a.stamp, blockIdx.x, 5);

@@ -166,6 +166,7 @@ struct GemvArgs {
   // (x/ldx ignored; K must equal attn_heads*128)
   const float* attn_pm; const float* attn_pl; const float* attn_po; int attn_nsplit; int attn_heads;
   int attn_fast_exp;            // merge weights with the hardware exponential (default mode) instead of expf
+  int fast_math;                // default mode: hardware rsq / exp / rcp in the RMSNorm scale and SiLU of the epilogue (dev.h rstd_of)
   Q3A_STAMP_FIELD
 };
 const char* launch_gemv(const GemvArgs& a, int NB, hipStream_t s);
@@ -197,6 +198,7 @@ struct SkinnyArgs {
   // N / 8 partial rows instead of N / 16 -- the caller sizes its buffers and the consumer's ss_nparts accordingly
   int qsplit;
   int qs_halves;  // (set by the launcher: 16-sequence halves per row tile)
+  int fast_math;  // default mode: hardware rsq / exp / rcp in the RMSNorm scale and SiLU of the epilogue (dev.h rstd_of)
   Q3A_STAMP_FIELD
 };
 // the same producer duty for kernels that write a whole row of the residual stream (token embedding)
