@@ -112,9 +112,15 @@ def _stage_check(model_dir, clips, precise, steps=4):
                 assert int(step_tok[s][b]) == res[b].all_step_ids[s], (b, s)
     # free-running whole path (graph-replayed decode)
     ids = eng.transcribe_batch(clips, None, max_new=steps, fixed_new_tokens=steps)
-    if precise:
-        for b in range(len(clips)):
+    for b in range(len(clips)):
+        if precise:
             assert ids[b] == res[b].all_step_ids[:steps]
+        else:  # default mode: the free-running ids equal the oracle's up to its first step inside the rounding noise
+            for s in range(steps):
+                top = res[b].step_logits[s].topk(2).values
+                if float(top[0] - top[1]) <= 2 * worst:
+                    break
+                assert ids[b][s] == res[b].all_step_ids[s], (b, s)
     t = eng.timings()
     assert t["batch"] == len(clips) and t["decode_steps"] == steps - 1 and t["total_ms"] > 0
     eng.close()
