@@ -12,9 +12,9 @@ the speech rate the survey fixes).  Rank 0 prints ONE JSON line.
 
 Launching.  N = 1: `python bench.py`.  N > 1: one process per GPU under torch.distributed.run (the driver's command above);
 a bare `python bench.py --gpus N` re-executes itself under torch.distributed.run on 127.0.0.1 with a free port, so the
-same command shape works at every N.  With N > 1 the line also carries `extra` legs: BASELINE configs[4]'s per-GPU
-workload (Qwen3-ASR-1.7B, 32 clips per GPU, weights shipped with ONE RCCL broadcast of the arena) and the native
-q3a_group_* path (one process, one host thread per GPU, RCCL called from C++).
+same command shape works at every N.  With N > 1 the line also carries an `extra` leg: BASELINE configs[4]'s per-GPU
+workload (Qwen3-ASR-1.7B, 32 clips per GPU, weights shipped with ONE RCCL broadcast of the arena); --native-group-leg adds
+the native q3a_group_* path (one process, one host thread per GPU, RCCL called from C++).
 
 What is inside the clock
   value               PCM already resident in HBM when the clock starts (the task contract), generated ids fetched to the
@@ -410,7 +410,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child passes (roofline falls back to the microbenchmark)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two PMC child passes (roofline.traffic = null)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra single-GPU legs (configs[2], configs[3])")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (N = 1: configs[2], configs[3], natural EOS; N > 1: configs[4]'s per-GPU workload)")
+    ap.add_argument("--native-group-leg", action="store_true",
+                    help="N > 1: also time q3a_group_transcribe (one process driving every GPU) on rank 0 while the other ranks wait on a CPU barrier")
     ap.add_argument("--ckpt-dir", default=None)
     ap.add_argument("--trace-out", default=None, help="write the per-kernel table of the in-situ rocprofv3 kernel trace to this file")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)
@@ -489,12 +491,16 @@ def main():
             multi_extra.append({"workload": "Qwen3-ASR-1.7b, 32 clips per GPU", "value": None, "error": str(ex)[:300]})
         torch.cuda.synchronize()
         dist.barrier()
-        if rank == 0:  # the native one-process group drives every GPU from this process; the other ranks idle at the barrier below
-            try:
-                multi_extra.append(native_group_leg(args.preset, args.ckpt_dir, world, B, args.seconds, args.new_tokens, args.steps, args.precise))
-            except Exception as ex:  # noqa: BLE001
-                multi_extra.append({"workload": "q3a_group_transcribe", "value": None, "error": str(ex)[:300]})
-        dist.barrier()
+        if args.native_group_leg:
+            # the native one-process group drives every GPU from rank 0's process; the other ranks wait on a gloo (CPU) barrier so
+            # that no collective kernel of theirs spins on the GPUs meanwhile
+            cpu_pg = dist.new_group(backend="gloo")
+            if rank == 0:
+                try:
+                    multi_extra.append(native_group_leg(args.preset, args.ckpt_dir, world, B, args.seconds, args.new_tokens, args.steps, args.precise))
+                except Exception as ex:  # noqa: BLE001
+                    multi_extra.append({"workload": "q3a_group_transcribe", "value": None, "error": str(ex)[:300]})
+            dist.barrier(group=cpu_pg)
 
     if rank == 0:
         audio_seconds = world * B * args.seconds * args.steps

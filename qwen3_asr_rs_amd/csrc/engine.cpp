@@ -1486,6 +1486,71 @@ int32_t q3a_selftest_gemm16(int32_t device, int32_t M, int32_t N, int32_t K, int
   HIPCHK(hipMemcpy(R.data(), dR.p, R.size() * 4, hipMemcpyDeviceToHost));
   float me = 0.f, rm = 0.f;
   for (size_t i = 0; i < Y.size(); ++i) { me = std::max(me, std::fabs(Y[i] - R[i])); rm = std::max(rm, std::fabs(R[i])); }
+  // ---- the epilogue variants, against the reference product R ----
+  {
+    const int P = 7;  // addend period
+    std::vector<float> bias(N), addend((size_t)P * N), resid((size_t)M * N);
+    std::vector<int> rowmap(M);
+    for (auto& v : bias) v = rnd();
+    for (auto& v : addend) v = rnd();
+    for (auto& v : resid) v = rnd();
+    for (int m = 0; m < M; ++m) rowmap[m] = (m % 11 == 5) ? -1 : M - 1 - m;  // reversed rows, some dropped
+    DevBuf dB, dA, dS, dM, dY2, dY16;
+    dB.ensure(bias.size() * 4); dA.ensure(addend.size() * 4); dS.ensure(resid.size() * 4); dM.ensure(rowmap.size() * 4);
+    dY2.ensure((size_t)M * N * 4); dY16.ensure((size_t)M * N * 2);
+    HIPCHK(hipMemcpy(dB.p, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dA.p, addend.data(), addend.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dS.p, resid.data(), resid.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dM.p, rowmap.data(), rowmap.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dY2.p, 0, (size_t)M * N * 4));
+    // (a) fp32 out: bias + periodic addend + row map + residual
+    GemmEpilogue e2; e2.out = dY2.as<float>(); e2.ldo = N; e2.bias = dB.as<float>(); e2.addend = dA.as<float>(); e2.addend_period = P;
+    e2.rowmap = dM.as<int>(); e2.resid = dS.as<float>();
+    KCHK(launch_gemm16(dX16.as<uint16_t>(), K, dW.as<uint16_t>(), M, N, K, e2, false, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<float> Y2((size_t)M * N);
+    HIPCHK(hipMemcpy(Y2.data(), dY2.p, Y2.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<char> hit(M, 0);
+    for (int m = 0; m < M; ++m) {
+      const int o = rowmap[m];
+      if (o < 0) continue;
+      hit[o] = 1;
+      for (int n = 0; n < N; ++n) {
+        const float want = R[(size_t)m * N + n] + bias[n] + addend[(size_t)(m % P) * N + n] + resid[(size_t)o * N + n];
+        me = std::max(me, std::fabs(Y2[(size_t)o * N + n] - want));
+      }
+    }
+    for (int o = 0; o < M; ++o)
+      if (!hit[o])
+        for (int n = 0; n < N; ++n)
+          if (Y2[(size_t)o * N + n] != 0.f) fail("selftest_gemm16: a row dropped by the row map was written");
+    // (b) bf16 out: bias only; one bf16 ulp
+    auto bf = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    GemmEpilogue e3; e3.out16 = dY16.as<uint16_t>(); e3.ldo = N; e3.bias = dB.as<float>();
+    KCHK(launch_gemm16(dX16.as<uint16_t>(), K, dW.as<uint16_t>(), M, N, K, e3, false, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<uint16_t> Y16((size_t)M * N);
+    HIPCHK(hipMemcpy(Y16.data(), dY16.p, Y16.size() * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < Y16.size(); ++i) {
+      const float want = R[i] + bias[i % N];
+      if (std::fabs(bf(Y16[i]) - want) > std::fabs(want) / 128.f + 1e-4f * std::max(rm, 1.f)) fail("selftest_gemm16: bf16 output with bias is off by more than an ulp");
+    }
+    // (c) SwiGLU pairs ([16 gate | 16 up] row blocks of W), bf16 out
+    if (N % 32 == 0) {
+      GemmEpilogue e4; e4.out16 = dY16.as<uint16_t>(); e4.ldo = N / 2;
+      KCHK(launch_gemm16(dX16.as<uint16_t>(), K, dW.as<uint16_t>(), M, N, K, e4, true, nullptr));
+      HIPCHK(hipDeviceSynchronize());
+      HIPCHK(hipMemcpy(Y16.data(), dY16.p, (size_t)M * (N / 2) * 2, hipMemcpyDeviceToHost));
+      for (int m = 0; m < M; ++m)
+        for (int c = 0; c < N / 2; ++c) {
+          const float g = R[(size_t)m * N + (c / 16) * 32 + c % 16], u = R[(size_t)m * N + (c / 16) * 32 + 16 + c % 16];
+          const float want = g / (1.f + std::exp(-g)) * u;
+          if (std::fabs(bf(Y16[(size_t)m * (N / 2) + c]) - want) > std::fabs(want) / 64.f + 1e-3f * std::max(rm * rm, 1.f))
+            fail("selftest_gemm16: SwiGLU epilogue is off");
+        }
+    }
+    dB.release(); dA.release(); dS.release(); dM.release(); dY2.release(); dY16.release();
+  }
   if (max_abs_err) *max_abs_err = me;
   if (ref_abs_max) *ref_abs_max = rm;
   if (reps > 0) {

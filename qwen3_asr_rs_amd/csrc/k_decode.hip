@@ -143,10 +143,17 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const float* __rest
 __global__ __launch_bounds__(1024) void argmax_finalize_kernel(FinalizeArgs a) {
   __shared__ float bv[16];
   __shared__ int bi[16];
-  __shared__ int tok_s, pos_s;
+  __shared__ int tok_s;
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* pv = a.part_val + (size_t)s * a.part_stride;
   const int* pi = a.part_idx + (size_t)s * a.part_stride;
+  // everything that does not depend on the chosen token is requested up front, next to the partial maxima: the
+  // sequence's counters and the RoPE row of its next position (one memory round trip instead of three in a chain)
+  const int np = a.pos[s] + a.advance;
+  const int sc = a.step_count[s];
+  const int was_done = a.done[s];
+  float rope_v = 0.f;
+  if (a.rope_cur && tid < 128) rope_v = tid < 64 ? a.cos_t[(size_t)np * 64 + tid] : a.sin_t[(size_t)np * 64 + tid - 64];
   float best = -INFINITY;
   int idx = 0x7fffffff;
   for (int i = tid; i < a.n_part; i += 1024) {
@@ -168,13 +175,10 @@ __global__ __launch_bounds__(1024) void argmax_finalize_kernel(FinalizeArgs a) {
     if (idx < 0 || idx >= a.V) idx = 0;  // all-NaN guard
     tok_s = idx;
     a.next_tok[s] = idx;
-    const int sc = a.step_count[s];
     if (sc < a.out_stride) a.out_ids[(size_t)s * a.out_stride + sc] = idx;
     a.step_count[s] = sc + 1;
-    const int np = a.pos[s] + a.advance;
     a.pos[s] = np;
-    pos_s = np;
-    if ((idx == a.eos0 || idx == a.eos1) && !a.done[s]) {  // this sequence's first EOS (inference.rs:163-165)
+    if ((idx == a.eos0 || idx == a.eos1) && !was_done) {  // this sequence's first EOS (inference.rs:163-165)
       a.done[s] = 1;
       if (a.n_done) {
         const int n = atomicAdd(a.n_done, 1) + 1;
@@ -186,8 +190,7 @@ __global__ __launch_bounds__(1024) void argmax_finalize_kernel(FinalizeArgs a) {
   __syncthreads();
   // RoPE row of the position the next decode step works at, at a fixed address: the attention kernels of that step
   // request it together with q/k/v instead of after a dependent load of pos
-  if (a.rope_cur && tid < 128)
-    a.rope_cur[(size_t)s * 128 + tid] = tid < 64 ? a.cos_t[(size_t)pos_s * 64 + tid] : a.sin_t[(size_t)pos_s * 64 + tid - 64];
+  if (a.rope_cur && tid < 128) a.rope_cur[(size_t)s * 128 + tid] = rope_v;
   embed_row(a.embed, tok_s, a.H, a.x_next, s, a.nn, bv);  // bv: its 16 floats are free again after the barrier above
 }
 

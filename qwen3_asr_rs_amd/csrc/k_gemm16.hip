@@ -13,10 +13,18 @@
 //     (2 x 2), each wave (BM/32) x (BN/32) fragments of v_mfma_f32_16x16x32_bf16;
 //   * K loop, two LDS buffers: one barrier per K tile (its workgroup release carries the vmcnt(0) that lands the
 //     LDS-DMA issued one iteration earlier), then the next tile's loads are issued and fly under this tile's MFMAs;
+//   * NS = 3 / 4 (64x64 / 32x64 tiles of dense operands, launches of up to 768 / 512 workgroups): a ring of LDS stages
+//     with two / three K tiles in flight and a COUNTED vmcnt in front of a raw s_barrier.  With two stages a K step costs
+//     one full L2 round trip for eight MFMAs per wave: on the one-clip shapes (M ~ 400: 300-700 workgroups, 14-16 K steps)
+//     the K loop took 9-10.5 us per workgroup, 4.9-5.9 us through the ring (profiles/r3_phase_probe_one_clip_gemms.txt);
+//   * the W fragment is the FIRST MFMA operand: the accumulator holds the transposed tile, a lane owns four consecutive
+//     output columns, and the epilogue requests all its operands (bias, addend, residual) before the first use;
 //   * the im2col view of the 3x3/s2/p1 convolutions reads padded taps from a zero page.
 // Measured (MI355X, random data): 460-590 TFLOP/s on the batch-32 encoder/prefill shapes, 637 at 8192^3,
 // against 340-380 / 456 for the fp32-activation kernel of k_gemm.hip.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "dev.h"
 #include "kernels.h"
@@ -60,7 +68,17 @@ struct ConvA16 {
 
 template <int BK> __device__ __forceinline__ int swz(int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 
-template <int BM, int BN, int BK, bool GLU, class ALoader>
+#define Q3A_G16_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+template <int N> __device__ __forceinline__ void g16_wait_vm() {
+  static_assert(N == 0 || N == 3 || N == 4 || N == 6 || N == 8, "vmcnt value");  // (A_LOADS + W_LOADS) x tiles in flight
+  if constexpr (N == 0) Q3A_G16_WAIT_VM(0);
+  else if constexpr (N == 3) Q3A_G16_WAIT_VM(3);
+  else if constexpr (N == 4) Q3A_G16_WAIT_VM(4);
+  else if constexpr (N == 6) Q3A_G16_WAIT_VM(6);
+  else Q3A_G16_WAIT_VM(8);
+}
+
+template <int BM, int BN, int BK, bool GLU, class ALoader, int NS = 2>
 __global__ __launch_bounds__(256) void gemm16_kernel(ALoader A, const uint16_t* __restrict__ Wt, int M, int N, int K,
                                                      GemmEpilogue ep) {
   constexpr int CPR = BK / 8;                   // 16-B chunks per tile row
@@ -70,8 +88,10 @@ __global__ __launch_bounds__(256) void gemm16_kernel(ALoader A, const uint16_t* 
   constexpr bool A_PART = BM < 4 * RPI, W_PART = BN < 4 * RPI;      // tile smaller than one 4-wave sweep
   constexpr int MI = BM / 32, NI = BN / 32;
   static_assert(MI >= 1 && NI >= 1 && (!GLU || NI >= 2), "tile shape");
-  __shared__ __attribute__((aligned(16))) uint16_t As[2][BM * BK];  // double-buffered: tile kt+1 lands while kt is consumed
-  __shared__ __attribute__((aligned(16))) uint16_t Ws[2][BN * BK];
+  static_assert(NS == 2 || ((NS == 3 || NS == 4) && !A_PART && !W_PART), "stage count");
+  constexpr int STAGE = (BM + BN) * BK;  // elements per stage: A tile, then W tile
+  __shared__ __attribute__((aligned(16))) uint16_t lds[NS * STAGE];  // the ONLY LDS object: NS stages, tile kt in stage kt % NS
+  Q3A_STAMP_AT(ep.stamp, blockIdx.x, 0);  // entry
 
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
@@ -118,26 +138,47 @@ __global__ __launch_bounds__(256) void gemm16_kernel(ALoader A, const uint16_t* 
       for (int i = 0; i < A_LOADS; ++i) {
         const int base = (i * 4 + wave) * RPI * BK;  // wave-uniform LDS element offset of this instruction's 1 KiB
         const uint16_t* ap = A.row_ptr(a_s0[i], a_s1[i], a_s2[i], k0) + a_src_chunk[i] * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)ap, (lptr_t)(&As[buf][base]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)ap, (lptr_t)(lds + buf * STAGE + base), 16, 0, 0);
       }
     }
     if (w_on) {
 #pragma unroll
       for (int i = 0; i < W_LOADS; ++i) {
         const int base = (i * 4 + wave) * RPI * BK;
-        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + k0), (lptr_t)(&Ws[buf][base]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + k0), (lptr_t)(lds + buf * STAGE + BM * BK + base), 16, 0, 0);
       }
     }
   };
-  issue_tile(0, 0);
+  if constexpr (NS == 2) {
+    issue_tile(0, 0);
+  } else {
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+      if (t < KT) issue_tile(t, t);
+  }
   for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    // one barrier per K tile: its workgroup release carries the vmcnt(0) that lands tile kt, and it orders every
-    // wave's fragment reads of tile kt-1 before that buffer is refilled below
-    __syncthreads();
-    if (kt + 1 < KT) issue_tile(kt + 1, buf ^ 1);
-    const uint16_t* as = As[buf];
-    const uint16_t* ws = Ws[buf];
+    const int buf = NS == 2 ? (kt & 1) : (kt % NS);
+    if constexpr (NS == 2) {
+      // one barrier per K tile: its workgroup release carries the vmcnt(0) that lands tile kt, and it orders every
+      // wave's fragment reads of tile kt-1 before that buffer is refilled below
+      __syncthreads();
+      if (kt + 1 < KT) issue_tile(kt + 1, buf ^ 1);
+    } else {
+      // tiles kt .. kt+NS-2 are in flight (fewer at the tail); the loads retire in order, so "at most as many
+      // outstanding as the later tiles issued" means tile kt has landed -- this wave's part; the raw barrier (a
+      // __syncthreads() would drain the queue) covers the other waves' parts and orders everyone's fragment reads of
+      // tile kt-1 before its stage is refilled with tile kt+NS-1
+      constexpr int L = A_LOADS + W_LOADS;
+      const int later = KT - 1 - kt;  // uniform
+      if (NS == 4 && later >= 2) g16_wait_vm<2 * L>();
+      else if (later >= 1) g16_wait_vm<L>();
+      else g16_wait_vm<0>();
+      asm volatile("s_barrier" ::: "memory");
+      if (kt + NS - 1 < KT) issue_tile(kt + NS - 1, (kt + NS - 1) % NS);
+    }
+    if (kt == 0) Q3A_STAMP_AT(ep.stamp, blockIdx.x, 1);  // first K tile landed
+    const uint16_t* as = lds + buf * STAGE;
+    const uint16_t* ws = as + BM * BK;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8_t bfrag[NI];
@@ -151,48 +192,147 @@ __global__ __launch_bounds__(256) void gemm16_kernel(ALoader A, const uint16_t* 
         const int row = wr * (BM / 2) + i * 16 + frag_row;
         const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(&as[row * BK + (((ks * 4 + frag_kc) ^ swz<BK>(row)) * 8)]);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[j], acc[i][j], 0, 0, 0);
+        // W fragment as the first operand: the accumulator holds the TRANSPOSED tile (rows = n, columns = m), i.e. a lane
+        // ends up with four CONSECUTIVE output columns of one output row -> 8-B (bf16) / 16-B (fp32) stores below
+        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfrag[j], af, acc[i][j], 0, 0, 0);
       }
     }
   }
 
-  // ---- epilogue (C/D layout of v_mfma_f32_16x16x32: col = lane&15, row = (lane>>4)*4 + reg) ----
-  const int col_in = lane & 15, row_in = (lane >> 4) * 4;
+  // ---- epilogue (C/D layout of v_mfma_f32_16x16x32: col = lane&15 -> m, row = (lane>>4)*4 + reg -> n) ----
+  Q3A_STAMP_AT(ep.stamp, blockIdx.x, 2);  // K loop done
+  // Two things cost 2.3-4.7 us per workgroup on the one-clip shapes in the untransposed form of this epilogue
+  // (profiles/r3_phase_probe_one_clip_gemms.txt): 16 two- or four-byte stores per lane and fragment row, and -- more -- the
+  // operand loads: `if (ep.bias) v += bias[n]` per fragment makes a chain of dependent L2 round trips (rowmap -> bias ->
+  // addend -> residual, each waited for where it is used).  Here every operand of every fragment is requested first, at a
+  // clamped (always valid) address, and the arithmetic starts after ONE wait.
+  const int m_in = lane & 15, n_in = (lane >> 4) * 4;
+  const bool vec = N % 4 == 0 && ep.ldo % 4 == 0;  // uniform; 4 | n and 4 | ldo: every vector access below is aligned
+  int mrow[MI], orow[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    mrow[i] = m0 + wr * (BM / 2) + i * 16 + m_in;
+    const int mc = mrow[i] < M ? mrow[i] : M - 1;
+    orow[i] = ep.rowmap ? ep.rowmap[mc] : mc;
+  }
+  if (!GLU && vec) {
+    float4 bb[NI], ad[MI][NI], rs[MI][NI];
+    int ncl[NI];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wr * (BM / 2) + i * 16 + row_in + r;
-      if (m >= M) continue;
-      const int orow = ep.rowmap ? ep.rowmap[m] : m;
-      if (orow < 0) continue;
-      if (!GLU) {
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wc * (BN / 2) + j * 16 + n_in;
+      ncl[j] = n < N ? n : 0;
+      if (ep.bias) bb[j] = *reinterpret_cast<const float4*>(ep.bias + ncl[j]);
+    }
+    if (ep.addend) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const int n = n0 + wc * (BN / 2) + j * 16 + col_in;
-          if (n >= N) continue;
-          float v = acc[i][j][r];
-          if (ep.bias) v += ep.bias[n];
-          if (ep.addend) v += ep.addend[(size_t)(m % ep.addend_period) * ep.ldo + n];
-          if (ep.act == 1) v = gelu_fast(v);  // default mode: the result is rounded to bf16 (dev.h)
-          if (ep.resid) v += ep.resid[(size_t)orow * ep.ldo + n];
-          if (ep.out16) ep.out16[(size_t)orow * ep.ldo + n] = (uint16_t)f32_to_bf16_bits(v);
-          else ep.out[(size_t)orow * ep.ldo + n] = v;
+      for (int i = 0; i < MI; ++i) {
+        const int mc = mrow[i] < M ? mrow[i] : M - 1;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) ad[i][j] = *reinterpret_cast<const float4*>(ep.addend + (size_t)(mc % ep.addend_period) * ep.ldo + ncl[j]);
+      }
+    }
+    if (ep.resid) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int oc = orow[i] < 0 ? 0 : orow[i];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) rs[i][j] = *reinterpret_cast<const float4*>(ep.resid + (size_t)oc * ep.ldo + ncl[j]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if (mrow[i] >= M || orow[i] < 0) continue;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wc * (BN / 2) + j * 16 + n_in;
+        if (n >= N) continue;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (ep.bias) { v[0] += bb[j].x; v[1] += bb[j].y; v[2] += bb[j].z; v[3] += bb[j].w; }
+        if (ep.addend) { v[0] += ad[i][j].x; v[1] += ad[i][j].y; v[2] += ad[i][j].z; v[3] += ad[i][j].w; }
+        if (ep.act == 1) {  // default mode: the result is rounded to bf16 (dev.h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
         }
-      } else {
+        if (ep.resid) { v[0] += rs[i][j].x; v[1] += rs[i][j].y; v[2] += rs[i][j].z; v[3] += rs[i][j].w; }
+        if (ep.out16) {
+          uint2 pk;
+          pk.x = pack_bf16x2(v[0], v[1]);
+          pk.y = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(ep.out16 + (size_t)orow[i] * ep.ldo + n) = pk;
+        } else {
+          *reinterpret_cast<float4*>(ep.out + (size_t)orow[i] * ep.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+  } else if (!GLU) {  // N or ldo not a multiple of 4: element by element
 #pragma unroll
-        for (int j = 0; j + 1 < NI; j += 2) {
-          const int nb = n0 + wc * (BN / 2) + j * 16;
-          if (nb + 16 + col_in >= N) continue;
-          float g = acc[i][j][r], u = acc[i][j + 1][r];
-          if (ep.bias) { g += ep.bias[nb + col_in]; u += ep.bias[nb + 16 + col_in]; }
-          const float v = silu_fast(g) * u;
-          if (ep.out16) ep.out16[(size_t)orow * ep.ldo + (nb >> 1) + col_in] = (uint16_t)f32_to_bf16_bits(v);
-          else ep.out[(size_t)orow * ep.ldo + (nb >> 1) + col_in] = v;
+    for (int i = 0; i < MI; ++i) {
+      if (mrow[i] >= M || orow[i] < 0) continue;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wc * (BN / 2) + j * 16 + n_in;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= N) continue;
+          float x = acc[i][j][r];
+          if (ep.bias) x += ep.bias[n + r];
+          if (ep.addend) x += ep.addend[(size_t)(mrow[i] % ep.addend_period) * ep.ldo + n + r];
+          if (ep.act == 1) x = gelu_fast(x);
+          if (ep.resid) x += ep.resid[(size_t)orow[i] * ep.ldo + n + r];
+          if (ep.out16) ep.out16[(size_t)orow[i] * ep.ldo + n + r] = (uint16_t)f32_to_bf16_bits(x);
+          else ep.out[(size_t)orow[i] * ep.ldo + n + r] = x;
+        }
+      }
+    }
+  } else {
+    // W rows come in [16 gate | 16 up] blocks (launcher: N % 32 == 0): fragment j holds gate, j + 1 the matching up columns
+    float4 bg[NI / 2 > 0 ? NI / 2 : 1], bu[NI / 2 > 0 ? NI / 2 : 1];
+    if (ep.bias) {
+#pragma unroll
+      for (int j = 0; j + 1 < NI; j += 2) {
+        const int nb = n0 + wc * (BN / 2) + j * 16;
+        const int nc = nb + 32 <= N ? nb + n_in : 0;
+        bg[j / 2] = *reinterpret_cast<const float4*>(ep.bias + nc);
+        bu[j / 2] = *reinterpret_cast<const float4*>(ep.bias + nc + 16);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if (mrow[i] >= M || orow[i] < 0) continue;
+#pragma unroll
+      for (int j = 0; j + 1 < NI; j += 2) {
+        const int nb = n0 + wc * (BN / 2) + j * 16;
+        if (nb + 32 > N) continue;
+        float g[4], u[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { g[r] = acc[i][j][r]; u[r] = acc[i][j + 1][r]; }
+        if (ep.bias) {
+          g[0] += bg[j / 2].x; g[1] += bg[j / 2].y; g[2] += bg[j / 2].z; g[3] += bg[j / 2].w;
+          u[0] += bu[j / 2].x; u[1] += bu[j / 2].y; u[2] += bu[j / 2].z; u[3] += bu[j / 2].w;
+        }
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_fast(g[r]) * u[r];
+        const size_t o = (size_t)orow[i] * ep.ldo + (nb >> 1) + n_in;
+        if (ep.out16) {
+          if (ep.ldo % 4 == 0) {
+            uint2 pk;
+            pk.x = pack_bf16x2(v[0], v[1]);
+            pk.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(ep.out16 + o) = pk;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ep.out16[o + r] = (uint16_t)f32_to_bf16_bits(v[r]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ep.out[o + r] = v[r];
         }
       }
     }
   }
+  Q3A_STAMP_AT(ep.stamp, blockIdx.x, 3);  // stores issued
 }
 
 // ---- small-M, K-heavy problems (one 30 s clip: M ~ 400, N ~ 1000, K 2048-7680) -------------------------------------
@@ -205,7 +345,7 @@ __global__ __launch_bounds__(256) void gemm16_kernel(ALoader A, const uint16_t* 
 // kept at position (c & ~15) | ((c ^ r) & 15).
 __device__ __forceinline__ int kswz(int c, int row) { return (c & ~15) | ((c ^ row) & 15); }
 
-template <int BN, int BKT, class ALoader>
+template <int BN, int BKT, class ALoader, int NS = 2>
 __global__ __launch_bounds__(256) void gemm16k_kernel(ALoader A, const uint16_t* __restrict__ Wt, int M, int N, int K,
                                                       GemmEpilogue ep) {
   constexpr int BM = 32;
@@ -216,9 +356,11 @@ __global__ __launch_bounds__(256) void gemm16k_kernel(ALoader A, const uint16_t*
   constexpr int KS = BKT / 4 / 32;         // MFMA k-steps per wave per K step (2 / 1)
   constexpr int MI = BM / 16, NI = BN / 16;
   static_assert(A_LOADS >= 1 && W_LOADS >= 1 && KS >= 1, "tile shape");
-  static_assert(2 * BM * BKT * 2 >= 4 * BM * BN * 4, "reduction buffer must fit in the A stages");
-  __shared__ __attribute__((aligned(16))) uint16_t As[2][BM * BKT];
-  __shared__ __attribute__((aligned(16))) uint16_t Ws[2][BN * BKT];
+  static_assert(NS == 2 || NS == 4, "stage count");
+  constexpr int STAGE = (BM + BN) * BKT;  // elements per stage: A tile, then W tile
+  static_assert(NS * STAGE * 2 >= 4 * BM * BN * 4, "reduction buffer must fit in the stages");
+  __shared__ __attribute__((aligned(16))) uint16_t lds[NS * STAGE];  // the ONLY LDS object (k_gemm16 header: NS = 4)
+  Q3A_STAMP_AT(ep.stamp, blockIdx.x, 0);  // entry
 
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
@@ -259,19 +401,37 @@ __global__ __launch_bounds__(256) void gemm16k_kernel(ALoader A, const uint16_t*
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
       const uint16_t* ap = A.row_ptr(a_s0[i], a_s1[i], a_s2[i], k0) + a_chunk[i] * 8;
-      __builtin_amdgcn_global_load_lds((gptr_t)ap, (lptr_t)(&As[buf][(i * 4 + wave) * RPI * BKT]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)ap, (lptr_t)(lds + buf * STAGE + (i * 4 + wave) * RPI * BKT), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < W_LOADS; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + k0), (lptr_t)(&Ws[buf][(i * 4 + wave) * RPI * BKT]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + k0), (lptr_t)(lds + buf * STAGE + BM * BKT + (i * 4 + wave) * RPI * BKT), 16, 0,
+                                       0);
   };
-  issue_tile(0, 0);
+  if constexpr (NS == 2) {
+    issue_tile(0, 0);
+  } else {
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+      if (t < KT) issue_tile(t, t);
+  }
   for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    __syncthreads();  // lands tile kt (vmcnt(0) rides on the barrier) and retires every wave's reads of tile kt-1
-    if (kt + 1 < KT) issue_tile(kt + 1, buf ^ 1);
-    const uint16_t* as = As[buf];
-    const uint16_t* ws = Ws[buf];
+    const int buf = NS == 2 ? (kt & 1) : (kt % NS);
+    if constexpr (NS == 2) {
+      __syncthreads();  // lands tile kt (vmcnt(0) rides on the barrier) and retires every wave's reads of tile kt-1
+      if (kt + 1 < KT) issue_tile(kt + 1, buf ^ 1);
+    } else {  // ring of NS stages, counted vmcnt + raw barrier: see gemm16_kernel
+      constexpr int L = A_LOADS + W_LOADS;
+      const int later = KT - 1 - kt;  // uniform
+      if (later >= 2) g16_wait_vm<2 * L>();
+      else if (later == 1) g16_wait_vm<L>();
+      else g16_wait_vm<0>();
+      asm volatile("s_barrier" ::: "memory");
+      if (kt + NS - 1 < KT) issue_tile(kt + NS - 1, (kt + NS - 1) % NS);
+    }
+    if (kt == 0) Q3A_STAMP_AT(ep.stamp, blockIdx.x, 1);  // first K step landed
+    const uint16_t* as = lds + buf * STAGE;
+    const uint16_t* ws = as + BM * BKT;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int c = wave * (CPR / 4) + ks * 4 + frag_kc;  // this wave's quarter of the K step
@@ -291,8 +451,9 @@ __global__ __launch_bounds__(256) void gemm16k_kernel(ALoader A, const uint16_t*
     }
   }
   // ---- sum the four K quarters through LDS: red[wave][row][col] ----
+  Q3A_STAMP_AT(ep.stamp, blockIdx.x, 2);  // K loop done
   __syncthreads();
-  float* red = reinterpret_cast<float*>(&As[0][0]);
+  float* red = reinterpret_cast<float*>(lds);
   {
     const int col_in = lane & 15, row_in = (lane >> 4) * 4;
 #pragma unroll
@@ -338,12 +499,29 @@ __global__ __launch_bounds__(256) void gemm16k_kernel(ALoader A, const uint16_t*
       *reinterpret_cast<float4*>(ep.out + (size_t)orow * ep.ldo + n) = v;
     }
   }
+  Q3A_STAMP_AT(ep.stamp, blockIdx.x, 3);  // stores issued
 }
 
 template <int BM, int BN, int BK, bool GLU, class ALoader>
 void launch16(const ALoader& A, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm16_kernel<BM, BN, BK, GLU, ALoader>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
+  // Dense operands, BK = 64, tiles up to 64x64: a ring of LDS stages as deep as still lets every workgroup of the launch be
+  // resident at once (64x64: 16 KiB per stage, 160 KiB per CU) -- four stages up to 2 workgroups per CU, three up to 3;
+  // beyond that (e.g. the lm_head of a batched decode step, 2374 workgroups) residency is worth more than depth: two.
+  // A/B knob: Q3A_GEMM16_STAGES=2 keeps two everywhere.
+  constexpr bool ring = std::is_same<ALoader, DenseA16>::value && BK == 64 && BM <= 64 && BN <= 64;
+  static const bool two_stage = [] { const char* e = getenv("Q3A_GEMM16_STAGES"); return e && atoi(e) == 2; }();
+  if constexpr (ring) {
+    if (!two_stage && tiles <= 512) {
+      hipLaunchKernelGGL((gemm16_kernel<BM, BN, BK, GLU, ALoader, 4>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
+      return;
+    }
+    if (!two_stage && tiles <= 768) {
+      hipLaunchKernelGGL((gemm16_kernel<BM, BN, BK, GLU, ALoader, 3>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((gemm16_kernel<BM, BN, BK, GLU, ALoader, 2>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
 }
 
 inline long tiles_of(int M, int N, int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); }
@@ -400,8 +578,13 @@ const char* launch_gemm16_small(const uint16_t* X, int lda, const uint16_t* W, i
   static const bool ksplit_on = [] { const char* e = getenv("Q3A_GEMM16_KSPLIT"); return !e || atoi(e) != 0; }();
   if (ksplit_on && !glu && tiles_of(M, N, 32, 64) < 384 && K >= 512 && K % 128 == 0 && N % 4 == 0 && ep.ldo % 4 == 0) {
     const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
-    if (K % 256 == 0) hipLaunchKernelGGL((gemm16k_kernel<32, 256, DenseA16>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
-    else hipLaunchKernelGGL((gemm16k_kernel<32, 128, DenseA16>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
+    // K steps of 256 in two stages (32 KiB in flight per workgroup); where 256 does not divide K (the encoder's d_model 896)
+    // steps of 128 in a ring of four stages (48 KiB in flight) instead of two (16 KiB): 6.5 vs 7.9 us on enc out.  The ring
+    // measured no gain over the 256-steps (profiles/r3_phase_probe_one_clip_gemms.txt).  A/B knob Q3A_GEMM16_STAGES=2.
+    static const bool two_stage = [] { const char* e = getenv("Q3A_GEMM16_STAGES"); return e && atoi(e) == 2; }();
+    if (K % 256 == 0) hipLaunchKernelGGL((gemm16k_kernel<32, 256, DenseA16, 2>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
+    else if (!two_stage) hipLaunchKernelGGL((gemm16k_kernel<32, 128, DenseA16, 4>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
+    else hipLaunchKernelGGL((gemm16k_kernel<32, 128, DenseA16, 2>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
     return nullptr;
   }
   static const bool force_bk32 = [] { const char* e = getenv("Q3A_GEMM16_BK32"); return e && atoi(e) != 0; }();  // A/B knob

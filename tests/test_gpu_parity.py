@@ -41,10 +41,12 @@ def test_gemm_against_device_reference(shape, split):
 
 
 @pytest.mark.parametrize("shape", [
-    (128, 128, 64), (130, 200, 96),                      # 32x64 tiles, ragged M/N, BK = 32 path (K % 64 != 0)
-    (70, 96, 256), (33, 36, 512), (390, 896, 3584),      # 32x32 tiles, 4 waves split K (BKT = 256)
-    (390, 1024, 896),                                    # same with BKT = 128 (K % 256 != 0)
-    (405, 4096, 1024), (1000, 480, 4320), (3000, 3584, 896),  # 64x64 and 128x128 tiles
+    (128, 128, 64), (130, 200, 96),                      # 32x64 tiles: one K tile in the 4-stage ring; BK = 32 path (K % 64 != 0)
+    (70, 98, 64), (1100, 1602, 128),                     # N % 4 != 0: element-wise epilogue (32x64 ring; 64x64 tiles, 3 stages)
+    (96, 128, 128), (70, 96, 256),                       # 32x64 tiles, ring shorter than / as long as its stage count
+    (33, 36, 512), (390, 896, 3584), (390, 1024, 896),   # 32x32 tiles, 4 waves split K (steps of 128, ring of 4 stages)
+    (520, 3072, 128), (405, 4096, 1024),                 # 64x64 tiles, 2 and 16 K tiles through the ring
+    (1000, 480, 4320), (3000, 3584, 896),                # 128x128 / 256x256 tiles
 ])
 def test_gemm16_against_device_reference(shape):
     """bf16-activation LDS-DMA GEMM (default mode) vs the fp64-accumulating device reference on the same bf16 inputs:

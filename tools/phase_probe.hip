@@ -86,6 +86,7 @@ static void summarize(const char* title, const std::vector<const char*>& kind_na
 
 int main(int argc, char** argv) {
   const bool do_layer = argc < 2 || strstr(argv[1], "layer"), do_gemm = argc < 2 || strstr(argv[1], "gemm"), do_one = argc < 2 || strstr(argv[1], "one");
+  const bool do_small = argc < 2 || strstr(argv[1], "small");
   hipStream_t s;
   CHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   KCHK(q3a::skinny_init());
@@ -326,6 +327,63 @@ int main(int argc, char** argv) {
       if (first_round)
         printf("    mean per tile (first round): prologue %.2f  K-loop %.2f  stage0 %.2f  store0 %.2f  stage1 %.2f  store1 %.2f\n", ph_first[0] / first_round,
                ph_first[1] / first_round, ph_first[2] / first_round, ph_first[3] / first_round, ph_first[4] / first_round, ph_first[5] / first_round);
+    }
+  }
+  if (do_small) {
+    // ---------------- part 4: the one-clip GEMMs (gemm16 / gemm16k: M ~ 400) ----------------
+    // Q3A_GEMM16_STAGES=2 in the environment selects the two-stage kernels (the launchers read it once per process)
+    struct Shape { const char* name; int M, N, K; int epi; bool glu; };  // epi as in part 2
+    const Shape shapes[] = {{"enc qkv  390 x 2688 x 896  (bf16 out)", 390, 2688, 896, 0, false}, {"enc fc1  390 x 3584 x 896  (bf16 out, GELU)", 390, 3584, 896, 1, false},
+                            {"enc out  390 x  896 x 896  (fp32 residual, K split)", 390, 896, 896, 2, false}, {"enc fc2  390 x  896 x 3584 (fp32 residual, K split)", 390, 896, 3584, 2, false},
+                            {"dec qkv  405 x 4096 x 1024 (fp32 out)", 405, 4096, 1024, 3, false}, {"dec g/u  405 x 6144 x 1024 (GLU, bf16 out)", 405, 6144, 1024, 0, true},
+                            {"dec o    405 x 1024 x 2048 (fp32 residual, K split)", 405, 1024, 2048, 2, false}, {"dec down 405 x 1024 x 3072 (fp32 residual, K split)", 405, 1024, 3072, 2, false}};
+    uint16_t* X = pool;
+    uint16_t* W = pool + ((size_t)1 << 28);
+    float *out32, *bias;
+    uint16_t* out16;
+    CHK(hipMalloc(&out32, (size_t)512 * 8192 * 4)); CHK(hipMalloc(&out16, (size_t)512 * 8192 * 2)); CHK(hipMalloc(&bias, 8192 * 4));
+    CHK(hipMemset(out32, 0, (size_t)512 * 8192 * 4)); CHK(hipMemset(bias, 0, 8192 * 4));
+    u64* stamps;
+    const int max_wgs = 2048;
+    CHK(hipMalloc(&stamps, (size_t)max_wgs * 8 * sizeof(u64)));
+    q3a::knobs().gemm256_min_tiles = 1 << 30;
+    const char* st_env = getenv("Q3A_GEMM16_STAGES");
+    printf("\none-clip GEMMs, %s\n", st_env && atoi(st_env) == 2 ? "two LDS stages (Q3A_GEMM16_STAGES=2)" : "ring of four LDS stages (default)");
+    for (const Shape& sh : shapes) {
+      q3a::GemmEpilogue ep;
+      ep.ldo = sh.glu ? sh.N / 2 : sh.N; ep.bias = sh.epi == 3 ? nullptr : bias;
+      if (sh.epi == 2) { ep.out = out32; ep.resid = out32; } else if (sh.epi == 3) { ep.out = out32; } else { ep.out16 = out16; ep.act = sh.glu ? 0 : sh.epi; }
+      hipEvent_t a, b;
+      CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+      float best = 1e30f;
+      const int REP = 8;  // distinct weights per repetition: no L2 reuse of W between launches
+      for (int r = 0; r < 6; ++r) {
+        ep.stamp = nullptr;
+        CHK(hipEventRecord(a, s));
+        for (int i = 0; i < REP; ++i) KCHK(q3a::launch_gemm16_small(X, sh.K, W + (size_t)(r * REP + i) * sh.N * sh.K, sh.M, sh.N, sh.K, ep, sh.glu, s));
+        CHK(hipEventRecord(b, s));
+        CHK(hipStreamSynchronize(s));
+        float ms; CHK(hipEventElapsedTime(&ms, a, b));
+        if (r > 0) best = std::min(best, ms / REP);
+      }
+      CHK(hipMemsetAsync(stamps, 0, (size_t)max_wgs * 8 * sizeof(u64), s));
+      ep.stamp = stamps;
+      KCHK(q3a::launch_gemm16_small(X, sh.K, W + (size_t)50 * sh.N * sh.K, sh.M, sh.N, sh.K, ep, sh.glu, s));
+      CHK(hipStreamSynchronize(s));
+      std::vector<u64> h((size_t)max_wgs * 8);
+      CHK(hipMemcpy(h.data(), stamps, h.size() * sizeof(u64), hipMemcpyDeviceToHost));
+      int wgs = 0;
+      u64 t0 = ~0ull, t1 = 0, tin = 0;
+      double ph[3] = {0, 0, 0};
+      for (int w = 0; w < max_wgs; ++w) {
+        if (!h[w * 8] || !h[w * 8 + 3]) continue;
+        ++wgs;
+        t0 = std::min(t0, h[w * 8]); t1 = std::max(t1, h[w * 8 + 3]); tin = std::max(tin, h[w * 8]);
+        for (int p = 0; p < 3; ++p) ph[p] += (double)(h[w * 8 + p + 1] - h[w * 8 + p]) * 0.01;
+      }
+      const double tf = 2.0 * sh.M * sh.N * sh.K / (best * 1e-3) * 1e-12;
+      printf("%-56s %5d wgs  %6.2f us back to back (%4.0f TFLOP/s)  stamped span %6.2f  last wg in at %5.2f | mean per wg: first tile %5.2f  K loop %5.2f  epilogue %5.2f\n",
+             sh.name, wgs, best * 1e3, tf, (double)(t1 - t0) * 0.01, (double)(tin - t0) * 0.01, ph[0] / std::max(wgs, 1), ph[1] / std::max(wgs, 1), ph[2] / std::max(wgs, 1));
     }
   }
   return 0;
