@@ -68,14 +68,9 @@ struct ConvA16 {
 
 template <int BK> __device__ __forceinline__ int swz(int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 
-#define Q3A_G16_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-template <int N> __device__ __forceinline__ void g16_wait_vm() {
-  static_assert(N == 0 || N == 3 || N == 4 || N == 6 || N == 8, "vmcnt value");  // (A_LOADS + W_LOADS) x tiles in flight
-  if constexpr (N == 0) Q3A_G16_WAIT_VM(0);
-  else if constexpr (N == 3) Q3A_G16_WAIT_VM(3);
-  else if constexpr (N == 4) Q3A_G16_WAIT_VM(4);
-  else if constexpr (N == 6) Q3A_G16_WAIT_VM(6);
-  else Q3A_G16_WAIT_VM(8);
+template <int N> __device__ __forceinline__ void g16_wait_vm() {  // N = (A_LOADS + W_LOADS) x tiles in flight
+  static_assert(N >= 0 && N < 64, "vmcnt value");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <int BM, int BN, int BK, bool GLU, class ALoader, int NS = 2>
@@ -128,6 +123,49 @@ __global__ __launch_bounds__(256) void gemm16_kernel(ALoader A, const uint16_t* 
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // ---- operands of the epilogue (bias, positional addend, residual): every one of them is requested at a clamped
+  // (always valid) address before anything uses it -- with small tiles and no row map already HERE, ahead of the first K
+  // tile, so that they arrive under the K loop (they are older than every LDS-DMA below: the counted waits of the ring,
+  // "at most n NEWER loads outstanding", still mean what they say); otherwise at the top of the epilogue.
+  const int m_in = lane & 15, n_in = (lane >> 4) * 4;  // accumulator layout, see the MFMA call below
+  const bool vec = N % 4 == 0 && ep.ldo % 4 == 0;      // uniform; 4 | n and 4 | ldo: every vector access is aligned
+  int mrow[MI], orow[MI], ncl[NI];
+  float4 bb[NI], ad[MI][NI], rs[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    mrow[i] = m0 + wr * (BM / 2) + i * 16 + m_in;
+    orow[i] = mrow[i] < M ? mrow[i] : M - 1;
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wc * (BN / 2) + j * 16 + n_in;
+    ncl[j] = n < N ? n : 0;
+  }
+  auto load_operands = [&]() {
+    if (ep.bias) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bb[j] = *reinterpret_cast<const float4*>(ep.bias + ncl[j]);
+    }
+    if (ep.addend) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int mc = mrow[i] < M ? mrow[i] : M - 1;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) ad[i][j] = *reinterpret_cast<const float4*>(ep.addend + (size_t)(mc % ep.addend_period) * ep.ldo + ncl[j]);
+      }
+    }
+    if (ep.resid) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int oc = orow[i] < 0 ? 0 : orow[i];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) rs[i][j] = *reinterpret_cast<const float4*>(ep.resid + (size_t)oc * ep.ldo + ncl[j]);
+      }
+    }
+  };
+  const bool pre = !GLU && MI * NI <= 4 && vec && ep.rowmap == nullptr;  // uniform
+  if (pre) load_operands();
 
   const int frag_row = lane & 15, frag_kc = lane >> 4;
   const int KT = K / BK;
@@ -206,40 +244,12 @@ __global__ __launch_bounds__(256) void gemm16_kernel(ALoader A, const uint16_t* 
   // operand loads: `if (ep.bias) v += bias[n]` per fragment makes a chain of dependent L2 round trips (rowmap -> bias ->
   // addend -> residual, each waited for where it is used).  Here every operand of every fragment is requested first, at a
   // clamped (always valid) address, and the arithmetic starts after ONE wait.
-  const int m_in = lane & 15, n_in = (lane >> 4) * 4;
-  const bool vec = N % 4 == 0 && ep.ldo % 4 == 0;  // uniform; 4 | n and 4 | ldo: every vector access below is aligned
-  int mrow[MI], orow[MI];
+  if (ep.rowmap) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    mrow[i] = m0 + wr * (BM / 2) + i * 16 + m_in;
-    const int mc = mrow[i] < M ? mrow[i] : M - 1;
-    orow[i] = ep.rowmap ? ep.rowmap[mc] : mc;
+    for (int i = 0; i < MI; ++i) orow[i] = ep.rowmap[orow[i]];  // orow held the clamped row
   }
   if (!GLU && vec) {
-    float4 bb[NI], ad[MI][NI], rs[MI][NI];
-    int ncl[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wc * (BN / 2) + j * 16 + n_in;
-      ncl[j] = n < N ? n : 0;
-      if (ep.bias) bb[j] = *reinterpret_cast<const float4*>(ep.bias + ncl[j]);
-    }
-    if (ep.addend) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int mc = mrow[i] < M ? mrow[i] : M - 1;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) ad[i][j] = *reinterpret_cast<const float4*>(ep.addend + (size_t)(mc % ep.addend_period) * ep.ldo + ncl[j]);
-      }
-    }
-    if (ep.resid) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int oc = orow[i] < 0 ? 0 : orow[i];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) rs[i][j] = *reinterpret_cast<const float4*>(ep.resid + (size_t)oc * ep.ldo + ncl[j]);
-      }
-    }
+    if (!pre) load_operands();
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       if (mrow[i] >= M || orow[i] < 0) continue;
@@ -394,6 +404,26 @@ __global__ __launch_bounds__(256) void gemm16k_kernel(ALoader A, const uint16_t*
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // The operands of the epilogue (bias, positional addend, residual) do not depend on the product: they are requested
+  // here, ahead of the first K step, and have long arrived when the K loop ends.  (They are older than every LDS-DMA
+  // below, so the counted waits of the ring -- "at most n NEWER loads outstanding" -- still mean what they say.)  With a
+  // row map the residual address needs a loaded value first: that one launch per clip keeps the loads in the epilogue.
+  constexpr int TPR = BN / 4;                     // threads per output row (4 columns each)
+  constexpr int NIT = (BM * TPR + 255) / 256;    // epilogue items per thread
+  const bool pre = ep.rowmap == nullptr;          // uniform
+  float4 pb[NIT], pa[NIT], pr[NIT];
+  if (pre) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * 256;
+      const int row = (e / TPR) % BM, c4 = (e % TPR) * 4;
+      const int mc = m0 + row < M ? m0 + row : M - 1, nc = n0 + c4 < N ? n0 + c4 : 0;
+      if (ep.bias) pb[it] = *reinterpret_cast<const float4*>(ep.bias + nc);
+      if (ep.addend) pa[it] = *reinterpret_cast<const float4*>(ep.addend + (size_t)(mc % ep.addend_period) * ep.ldo + nc);
+      if (ep.resid) pr[it] = *reinterpret_cast<const float4*>(ep.resid + (size_t)mc * ep.ldo + nc);
+    }
+  }
+
   const int frag_row = lane & 15, frag_kc = lane >> 4;
   const int KT = K / BKT;
   auto issue_tile = [&](int kt, int buf) {
@@ -464,32 +494,32 @@ __global__ __launch_bounds__(256) void gemm16k_kernel(ALoader A, const uint16_t*
         for (int r = 0; r < 4; ++r) red[(wave * BM + i * 16 + row_in + r) * BN + j * 16 + col_in] = acc[i][j][r];
   }
   __syncthreads();
-  constexpr int TPR = BN / 4;  // threads per output row (4 columns each)
-  for (int e = tid; e < BM * TPR; e += 256) {
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = tid + it * 256;
+    if (e >= BM * TPR) continue;
     const int row = e / TPR, c4 = (e % TPR) * 4;
     const int m = m0 + row, n = n0 + c4;
     if (m >= M || n >= N) continue;
     const int orow = ep.rowmap ? ep.rowmap[m] : m;
     if (orow < 0) continue;
+    float4 b4, a4, r4;
+    if (pre) { b4 = pb[it]; a4 = pa[it]; r4 = pr[it]; }
+    else {
+      if (ep.bias) b4 = *reinterpret_cast<const float4*>(ep.bias + n);
+      if (ep.addend) a4 = *reinterpret_cast<const float4*>(ep.addend + (size_t)(m % ep.addend_period) * ep.ldo + n);
+      if (ep.resid) r4 = *reinterpret_cast<const float4*>(ep.resid + (size_t)orow * ep.ldo + n);
+    }
     float4 v = *reinterpret_cast<const float4*>(&red[row * BN + c4]);
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
       const float4 p = *reinterpret_cast<const float4*>(&red[(w * BM + row) * BN + c4]);
       v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     }
-    if (ep.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(ep.bias + n);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    }
-    if (ep.addend) {
-      const float4 b = *reinterpret_cast<const float4*>(ep.addend + (size_t)(m % ep.addend_period) * ep.ldo + n);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    }
+    if (ep.bias) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
+    if (ep.addend) { v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w; }
     if (ep.act == 1) { v.x = gelu_fast(v.x); v.y = gelu_fast(v.y); v.z = gelu_fast(v.z); v.w = gelu_fast(v.w); }
-    if (ep.resid) {
-      const float4 b = *reinterpret_cast<const float4*>(ep.resid + (size_t)orow * ep.ldo + n);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    }
+    if (ep.resid) { v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
     if (ep.out16) {
       uint2 pk;
       pk.x = pack_bf16x2(v.x, v.y);
@@ -582,6 +612,9 @@ const char* launch_gemm16_small(const uint16_t* X, int lda, const uint16_t* W, i
     // steps of 128 in a ring of four stages (48 KiB in flight) instead of two (16 KiB): 6.5 vs 7.9 us on enc out.  The ring
     // measured no gain over the 256-steps (profiles/r3_phase_probe_one_clip_gemms.txt).  A/B knob Q3A_GEMM16_STAGES=2.
     static const bool two_stage = [] { const char* e = getenv("Q3A_GEMM16_STAGES"); return e && atoi(e) == 2; }();
+    // (Measured and dropped: 32x64 tiles, at most one per CU, ring of four 128-steps -- the launch then moves 96 instead of
+    // 2 x 64 operand rows per K step on its busiest CUs, but 48-74 CUs idle: 926 vs 930 us over the 92 launches of a clip.
+    // These launches run at ~75 GB/s of LDS-DMA per CU whatever the tile, profiles/r3_phase_probe_one_clip_gemms.txt.)
     if (K % 256 == 0) hipLaunchKernelGGL((gemm16k_kernel<32, 256, DenseA16, 2>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
     else if (!two_stage) hipLaunchKernelGGL((gemm16k_kernel<32, 128, DenseA16, 4>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
     else hipLaunchKernelGGL((gemm16k_kernel<32, 128, DenseA16, 2>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
