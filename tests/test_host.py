@@ -203,12 +203,12 @@ def test_output_parsing_mirror():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r2_bench_final.json is the bench.py line of this round: every field the driver and the judge read
+    """profiles/r3_bench_final.json is the bench.py line of this round: every field the driver and the judge read
     must be there with the right type (BASELINE.json metric, roofline and cpu_baseline objects), the roofline must come
     from the in-situ trace and be internally consistent, and the extra legs must name BASELINE.json's other configs."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    j = json.load(open(os.path.join(root, "profiles", "r2_bench_final.json")))
+    j = json.load(open(os.path.join(root, "profiles", "r3_bench_final.json")))
     base = json.load(open(os.path.join(root, "BASELINE.json")))
     assert j["metric"].split(",")[0] == base["metric"].split(",")[0]
     assert j["unit"] == "audio-seconds/sec" and j["higher_is_better"] is True and j["scaling"] == "weak"
@@ -226,7 +226,10 @@ def test_committed_bench_line_follows_the_contract():
     assert r["traffic"] is None or "pmc" in r["traffic_source"]
     assert 0 < r["decode_stage"]["frac"] < 1
     c = j["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and len(c["runs"]) >= 3
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and len(c["runs"]) >= 5
+    ne = j["natural_eos"]  # the reference's contract (fixed_new_tokens = 0) beside the fixed-N number, BASELINE.md section 3
+    assert ne["stopped_at_planned_token"] is True and ne["generated_tokens"] == j["config"]["new_tokens"]
+    assert 0 < ne["value"] <= j["value"] * 1.02 and ne["decode_steps_executed"] - ne["decode_steps_needed"] <= 2
     ex = j["extra"]
     assert len(ex) == 2 and "batch=32" in ex[0]["workload"] and "1.7b" in ex[1]["workload"] and all(e["value"] > 0 for e in ex)
 
