@@ -605,9 +605,18 @@ struct q3a_engine {
       // streamed once through double-buffered LDS; the skinny kernel re-reads x per 16 vocabulary rows (3x slower here)
       timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(L.final_norm), s_ln.as<float>(), S, H, d.rms_eps, stream, s_ln.as<uint16_t>())); });
       GemmEpilogue ep; ep.out = logits.as<float>(); ep.ldo = V;
-      timed(Q3A_KC_GEMM, wbytes, [&] { KCHK(launch_gemm16(s_ln.as<uint16_t>(), H, wh(L.lm_head), S, V, H, ep, false, stream)); });
-      n_part = 128;
-      timed(Q3A_KC_ARGMAX, 0, [&] { KCHK(launch_argmax_partials(logits.as<float>(), V, S, part_val.as<float>(), part_idx.as<int>(), part_stride, n_part, stream)); });
+      if (S <= 32 && V % 4 == 0 && H % 64 == 0 && part_stride >= (V + 63) / 64) {
+        // the argmax partials are the GEMM's epilogue (one per 64-column tile and row), and inside q3a_transcribe_batch /
+        // q3a_run_resident nobody reads the logits: they are not stored (19 MB per step at 32 sequences)
+        ep.part_val = part_val.as<float>(); ep.part_idx = part_idx.as<int>(); ep.part_stride = part_stride;
+        if (!head_logits_) ep.out = nullptr;
+        n_part = (V + 63) / 64;
+        timed(Q3A_KC_GEMM, wbytes, [&] { KCHK(launch_gemm16(s_ln.as<uint16_t>(), H, wh(L.lm_head), S, V, H, ep, false, stream)); });
+      } else {
+        timed(Q3A_KC_GEMM, wbytes, [&] { KCHK(launch_gemm16(s_ln.as<uint16_t>(), H, wh(L.lm_head), S, V, H, ep, false, stream)); });
+        n_part = 128;
+        timed(Q3A_KC_ARGMAX, 0, [&] { KCHK(launch_argmax_partials(logits.as<float>(), V, S, part_val.as<float>(), part_idx.as<int>(), part_stride, n_part, stream)); });
+      }
     } else {
       timed(Q3A_KC_NORM, 0, [&] { KCHK(launch_rmsnorm(x_dec.as<float>(), wf(L.final_norm), s_ln.as<float>(), S, H, d.rms_eps, stream)); });
       timed(Q3A_KC_GEMM, wbytes, [&] { batched_proj(s_ln.as<float>(), H, wh(L.lm_head), V, H, nullptr, 0, logits.as<float>(), V, nullptr); });
@@ -875,8 +884,8 @@ struct q3a_engine {
 
   std::string make_graph_sig() const {
     char buf[320];  // everything the captured step's launches depend on: geometry, latched knobs, buffer addresses
-    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d/%d/%d/%p/%p/%p/%p/%p/%p/%p/%p", B, gsize, k_parallel_groups, k_skinny_q, k_fuse_qkv_attn,
-             k_dattn_batched_min_wgs, max_ctx, max_new, kcache.p, vcache.p, x_dec.p, logits.p, s_qkv.p, out_ids.p, rope_cos.p, attn_po.p);
+    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d/%d/%d/%p/%p/%p/%p/%p/%p/%p/%p", B, gsize, k_parallel_groups, k_skinny_q, k_fuse_qkv_attn,
+             k_dattn_batched_min_wgs, (int)head_logits_, max_ctx, max_new, kcache.p, vcache.p, x_dec.p, logits.p, s_qkv.p, out_ids.p, rope_cos.p, attn_po.p);
     return buf;
   }
 
@@ -1010,6 +1019,7 @@ struct q3a_engine {
     }
   }
   bool fixed_mode_ = false;
+  bool head_logits_ = true;  // store the logits of a batched decode step (step API, debug taps); off inside run_resident
 
   ~q3a_engine() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -1217,6 +1227,7 @@ int32_t q3a_prefill(q3a_engine* e, const int32_t* ids, const int32_t* lens, int3
   Q3A_TRY(e)
   HIPCHK(hipSetDevice(e->device));
   e->fixed_mode_ = false;
+  e->head_logits_ = true;
   e->setup_prompts(ids, lens, B, e->opts.max_new_tokens);
   e->run_prefill();
   HIPCHK(hipStreamSynchronize(e->stream));
@@ -1237,6 +1248,7 @@ int32_t q3a_decode_step(q3a_engine* e, int32_t* next_ids, uint8_t* done, float* 
     for (int s = 0; s < e->B; ++s)
       if (pos[s] + 1 > e->max_ctx) fail("q3a_decode_step: KV cache capacity exhausted (max_new_tokens reached)");
   }
+  e->head_logits_ = true;
   e->decode_steps(1);
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipGetLastError());
@@ -1267,6 +1279,7 @@ int32_t q3a_run_resident(q3a_engine* e, const int32_t* lang_prefix_ids, int32_t 
   Q3A_TRY(e)
   HIPCHK(hipSetDevice(e->device));
   e->fixed_mode_ = fixed_new_tokens > 0;
+  e->head_logits_ = e->opts.debug_taps != 0;
   e->run_resident(lang_prefix_ids, n_prefix, max_new, fixed_new_tokens);
   Q3A_CATCH(e)
 }
@@ -1287,6 +1300,7 @@ int32_t q3a_transcribe_batch(q3a_engine* e, const float* pcm16k, const int64_t* 
   HIPCHK(hipSetDevice(e->device));
   e->upload_pcm(pcm16k, n_samples, B);
   e->fixed_mode_ = fixed_new_tokens > 0;
+  e->head_logits_ = e->opts.debug_taps != 0;
   e->run_resident(lang_prefix_ids, n_prefix, max_new, fixed_new_tokens);
   e->fetch_ids(out_ids, stride, out_lens);
   Q3A_CATCH(e)

@@ -250,6 +250,9 @@ __global__ __launch_bounds__(256) void gemm16_kernel(ALoader A, const uint16_t* 
   }
   if (!GLU && vec) {
     if (!pre) load_operands();
+    constexpr bool ARGMAX = BM == 32 && MI == 1;  // only the M <= 32 tile carries the code
+    float bestv = -INFINITY;
+    int besti = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       if (mrow[i] >= M || orow[i] < 0) continue;
@@ -265,13 +268,42 @@ __global__ __launch_bounds__(256) void gemm16_kernel(ALoader A, const uint16_t* 
           for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
         }
         if (ep.resid) { v[0] += rs[i][j].x; v[1] += rs[i][j].y; v[2] += rs[i][j].z; v[3] += rs[i][j].w; }
+        if (ARGMAX && ep.part_val) {  // columns ascend with j and r: a strict > keeps the first index on ties
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (v[r] > bestv) { bestv = v[r]; besti = n + r; }
+        }
         if (ep.out16) {
           uint2 pk;
           pk.x = pack_bf16x2(v[0], v[1]);
           pk.y = pack_bf16x2(v[2], v[3]);
           *reinterpret_cast<uint2*>(ep.out16 + (size_t)orow[i] * ep.ldo + n) = pk;
-        } else {
+        } else if (ep.out) {
           *reinterpret_cast<float4*>(ep.out + (size_t)orow[i] * ep.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    if constexpr (ARGMAX) {
+      if (ep.part_val) {  // uniform
+        // row m = lane & 15 of this wave's 16 rows: its four column groups sit in lanes l, l+16, l+32, l+48; then the two
+        // column halves (waves wc = 0 / 1) meet in LDS (every wave has left the K loop: barrier first, the stages are free)
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+          const float ov = __shfl_xor(bestv, o, 64);
+          const int oi = __shfl_xor(besti, o, 64);
+          if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; }
+        }
+        __syncthreads();
+        float* pv = reinterpret_cast<float*>(lds);        // [wc][32 rows]
+        int* pi = reinterpret_cast<int*>(lds) + 64;
+        if (lane < 16) { pv[wc * 32 + wr * 16 + lane] = bestv; pi[wc * 32 + wr * 16 + lane] = besti; }
+        __syncthreads();
+        if (tid < 32 && m0 + tid < M) {
+          float v = pv[tid];
+          int ix = pi[tid];
+          if (pv[32 + tid] > v || (pv[32 + tid] == v && pi[32 + tid] < ix)) { v = pv[32 + tid]; ix = pi[32 + tid]; }
+          ep.part_val[(size_t)(m0 + tid) * ep.part_stride + tn] = v;
+          ep.part_idx[(size_t)(m0 + tid) * ep.part_stride + tn] = ix;
         }
       }
     }
@@ -594,7 +626,7 @@ const char* launch_gemm16(const uint16_t* X, int lda, const uint16_t* W, int M, 
                           bool glu, hipStream_t s) {
   if (M <= 0) return nullptr;
   if (K % 32 != 0 || lda % 8 != 0) return "gemm16: K must be a multiple of 32 and lda of 8";
-  if (K % 64 == 0 && gemm256_eligible(M, N, K)) return launch_gemm256(X, lda, W, M, N, K, ep, glu, s);
+  if (K % 64 == 0 && !ep.part_val && gemm256_eligible(M, N, K)) return launch_gemm256(X, lda, W, M, N, K, ep, glu, s);
   return launch_gemm16_small(X, lda, W, M, N, K, ep, glu, s);
 }
 
@@ -603,10 +635,12 @@ const char* launch_gemm16_small(const uint16_t* X, int lda, const uint16_t* W, i
   if (M <= 0) return nullptr;
   if (K % 32 != 0 || lda % 8 != 0) return "gemm16: K must be a multiple of 32 and lda of 8";
   if (glu && N % 32 != 0) return "gemm16: GLU needs N % 32 == 0";
+  if (ep.part_val && (M > 32 || glu || N % 4 != 0 || ep.ldo % 4 != 0 || K % 64 != 0 || ep.rowmap || ep.part_stride < (N + 63) / 64))
+    return "gemm16: argmax partials need M <= 32, 4 | N, 4 | ldo, 64 | K, no row map and part_stride >= ceil(N / 64)";
   DenseA16 A{X, lda};
   // few tiles and a long K: 32x32 tiles whose 4 waves split K (A/B knob: Q3A_GEMM16_KSPLIT=0 disables)
   static const bool ksplit_on = [] { const char* e = getenv("Q3A_GEMM16_KSPLIT"); return !e || atoi(e) != 0; }();
-  if (ksplit_on && !glu && tiles_of(M, N, 32, 64) < 384 && K >= 512 && K % 128 == 0 && N % 4 == 0 && ep.ldo % 4 == 0) {
+  if (ksplit_on && !glu && !ep.part_val && tiles_of(M, N, 32, 64) < 384 && K >= 512 && K % 128 == 0 && N % 4 == 0 && ep.ldo % 4 == 0) {
     const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
     // K steps of 256 in two stages (32 KiB in flight per workgroup); where 256 does not divide K (the encoder's d_model 896)
     // steps of 128 in a ring of four stages (48 KiB in flight) instead of two (16 KiB): 6.5 vs 7.9 us on enc out.  The ring

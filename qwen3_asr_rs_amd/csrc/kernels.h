@@ -27,6 +27,11 @@ struct GemmEpilogue {
   const int* rowmap = nullptr;   // GEMM row m -> output row (negative: drop the row); null = identity
   const float* addend = nullptr; // [addend_period][ldo] added before the activation (positional embedding)
   int addend_period = 1;
+  // k_gemm16.hip, M <= 32 (lm_head of a batched decode step): per output row the maximum of each 64-column tile and its
+  // column (first index on ties) -> part_val / part_idx[row * part_stride + tile]; `out` may then be null (no logits stored)
+  float* part_val = nullptr;
+  int* part_idx = nullptr;
+  int part_stride = 0;
   Q3A_STAMP_FIELD
 };
 // Y = X[M][K](fp32, row stride lda) . W[N][K]^T(bf16).  glu: W rows are [16 gate|16 up] blocks, out has N/2 columns.

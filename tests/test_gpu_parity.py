@@ -147,6 +147,28 @@ def test_batch_above_gemv_path(tiny_dir):
     _stage_check(tiny_dir, clips, True, steps=3)
 
 
+def test_batched_head_argmax_in_the_gemm_epilogue(tiny_dir):
+    """Default mode, 3..32 sequences: the lm_head GEMM writes one argmax partial per 64-column tile and row, and inside
+    transcribe_batch the logits are not stored at all.  The ids of transcribe_batch, the ids of the step API and the argmax
+    of the step API's logits (first index on ties, tensor.rs:370-372) are the same numbers."""
+    for B in (5, 32):
+        clips = [synthetic.synthetic_clip(300 + i, 1.0 + 0.21 * (i % 6)) for i in range(B)]
+        eng = HipEngine(tiny_dir, 0, max_new_tokens=16)  # no debug taps: the fused loop runs without a logits buffer write
+        ids = eng.transcribe_batch(clips, None, max_new=6, fixed_new_tokens=6)
+        eng.mel(clips)
+        prompts = [HipEngine.build_prompt(e.shape[0]) for e in eng.encode()]
+        logits, nxt = eng.prefill(prompts)
+        got = [[int(t)] for t in nxt]
+        assert [int(np.argmax(logits[b])) for b in range(B)] == [g[0] for g in got]
+        for _ in range(5):
+            lg, nx, _done = eng.decode_step()
+            for b in range(B):
+                assert int(np.argmax(lg[b])) == int(nx[b]), b
+                got[b].append(int(nx[b]))
+        assert got == ids
+        eng.close()
+
+
 def test_batched_decode_attention_and_sequence_groups(tiny_dir):
     """Batched decode step: (i) the one-workgroup-per-(sequence, kv head) attention kernel (online softmax over 128-key
     tiles, context written directly, no merge launch) forced on at tiny dims, both modes, long context (7+ tiles);
