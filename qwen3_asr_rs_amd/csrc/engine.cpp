@@ -170,8 +170,14 @@ struct q3a_engine {
   hipEvent_t fork_ev = nullptr;
 
   // ---- graph ----
-  hipGraphExec_t graph_exec = nullptr;
-  std::string graph_sig;
+  // instantiated decode-step graphs by signature (make_graph_sig): a batch shape met before -- or the same batch at a key-split
+  // count met before -- replays without a new capture; oldest entry dropped beyond kGraphCacheMax
+  static constexpr size_t kGraphCacheMax = 16;
+  std::vector<std::pair<std::string, hipGraphExec_t>> graph_cache;
+  // Key splits the one-sequence decode attention launches (k_dattn.hip decode_attn_kernel: one workgroup per kv head and
+  // 128-key split).  Sized by what the caches HOLD, not by their capacity: pos_hi_ = longest prompt + decode steps enqueued
+  // (host-side count, an upper bound of every sequence's position), so a generous max_new_tokens costs no empty splits.
+  int pos_hi_ = 0, live_nsplit_ = 0;
 
   // ---- measurement ----
   q3a_timings timings{};
@@ -527,6 +533,7 @@ struct q3a_engine {
     total_P = off;
     max_new = std::min(std::max(max_new_req, 1), opts.max_new_tokens);
     max_ctx = ((maxP + max_new + 1 + 127) / 128) * 128;  // whole 128-key tiles (the batched decode attention reads cache rows tile by tile)
+    pos_hi_ = maxP;
     {  // A/B knob: extra keys per (sequence, kv head) cache row block, so that the streams of the batched decode attention
        // do not all start a power of two apart (512 keys x 256 B = 128 KiB)
       static const int pad = [] { const char* e = getenv("Q3A_CTX_PAD"); return e ? atoi(e) : 0; }();
@@ -759,7 +766,7 @@ struct q3a_engine {
     da.qkv = qkv; da.pos = d_pos.as<int>() + s0; da.eps = d.rms_eps;
     da.rope_cur = rope_cur.as<float>() + (size_t)s0 * 128;
     da.pm = attn_pm.as<float>() + (size_t)s0 * d.n_q * attn_nsplit; da.pl = attn_pl.as<float>() + (size_t)s0 * d.n_q * attn_nsplit;
-    da.po = attn_po.as<float>() + (size_t)s0 * d.n_q * attn_nsplit * 128; da.nsplit = attn_nsplit;
+    da.po = attn_po.as<float>() + (size_t)s0 * d.n_q * attn_nsplit * 128; da.nsplit = live_nsplit_;  // (buffers sized for attn_nsplit)
     da.n_q = d.n_q; da.n_kv = d.n_kv; da.max_ctx = max_ctx; da.scale_div = sqrtf((float)d.head_dim);
     da.q_norm = wf(l.q_norm); da.k_norm = wf(l.k_norm);
     da.kcache = (uint8_t*)kc_layer(li) + (size_t)s0 * kv_seq; da.vcache = (uint8_t*)vc_layer(li) + (size_t)s0 * kv_seq;
@@ -768,7 +775,7 @@ struct q3a_engine {
       g.fast_math = precise() ? 0 : 1;
       g.x = x; g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
       g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = qkv; g.ldo = QKV;
-      if (k_fuse_qkv_attn != 0 && S == 1 && d.n_kv == 8 && d.n_q == 16 && (H == 1024 || H == 2048) && attn_nsplit <= 32) {
+      if (k_fuse_qkv_attn != 0 && S == 1 && d.n_kv == 8 && d.n_q == 16 && (H == 1024 || H == 2048) && live_nsplit_ <= 32) {
         // one kv head per XCD: projection rows and key splits of a head share that XCD's L2 (k_dattn.hip qkv_attn_kernel)
         QkvFuseArgs fa{};
         fa.x = x; fa.rms_w = wf(l.in_ln); fa.eps = d.rms_eps; fa.W = wh(l.qkv_w); fa.bias = g.bias; fa.K = H;
@@ -781,11 +788,11 @@ struct q3a_engine {
       }
       GemvArgs o{};
       o.fast_math = precise() ? 0 : 1;
-      if (std::min(S, 4) * d.n_q * attn_nsplit <= GEMV_ATTN_MAX_TABLE) {  // merge the key splits inside the o_proj GEMV
+      if (std::min(S, 4) * d.n_q * live_nsplit_ <= GEMV_ATTN_MAX_TABLE) {  // merge the key splits inside the o_proj GEMV
         o.attn_pm = da.pm; o.attn_pl = da.pl; o.attn_po = da.po;
-        o.attn_nsplit = attn_nsplit; o.attn_heads = d.n_q; o.attn_fast_exp = precise() ? 0 : 1;
+        o.attn_nsplit = live_nsplit_; o.attn_heads = d.n_q; o.attn_fast_exp = precise() ? 0 : 1;
       } else {  // very long contexts: separate merge launch
-        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, attn_nsplit, S, d.n_q, s_ctx_g(grp), ks)); });
+        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, live_nsplit_, S, d.n_q, s_ctx_g(grp), ks)); });
         o.x = s_ctx_g(grp);
       }
       o.ldx = QD; o.W = wh(l.o_w); o.N = H; o.K = QD; o.bias = o_bias ? wf(l.o_b) : nullptr;
@@ -819,7 +826,7 @@ struct q3a_engine {
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn_batched(da, S, kv_f32(), ks)); });
     } else {
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
-      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, attn_nsplit, S, d.n_q, s_ctx_g(grp), ks, b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr, b16)); });
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, live_nsplit_, S, d.n_q, s_ctx_g(grp), ks, b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr, b16)); });
     }
     SkinnyArgs o{};
     o.fast_math = precise() ? 0 : 1;
@@ -884,39 +891,58 @@ struct q3a_engine {
 
   std::string make_graph_sig() const {
     char buf[320];  // everything the captured step's launches depend on: geometry, latched knobs, buffer addresses
-    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d/%d/%d/%p/%p/%p/%p/%p/%p/%p/%p", B, gsize, k_parallel_groups, k_skinny_q, k_fuse_qkv_attn,
-             k_dattn_batched_min_wgs, (int)head_logits_, max_ctx, max_new, kcache.p, vcache.p, x_dec.p, logits.p, s_qkv.p, out_ids.p, rope_cos.p, attn_po.p);
+    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d.%d/%d/%d/%p/%p/%p/%p/%p/%p/%p/%p", B, gsize, k_parallel_groups, k_skinny_q, k_fuse_qkv_attn,
+             k_dattn_batched_min_wgs, (int)head_logits_, live_nsplit_, max_ctx, max_new, kcache.p, vcache.p, x_dec.p, logits.p, s_qkv.p, out_ids.p, rope_cos.p, attn_po.p);
     return buf;
+  }
+
+  // does any group of the batch run the key-split attention (GEMV path, or a group too small for the batched kernel)?
+  bool uses_key_splits() const {
+    if (B <= kGemvMaxSeq) return true;
+    const int ng = n_groups(B);
+    const int smallest = ng == 1 ? B : std::min(gsize, B - (ng - 1) * gsize);
+    return smallest * d.n_kv < k_dattn_batched_min_wgs;
+  }
+  hipGraphExec_t graph_for_step() {
+    const std::string sig = make_graph_sig();
+    for (auto& e : graph_cache)
+      if (e.first == sig) return e.second;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    try {
+      enqueue_decode_step();
+    } catch (...) {
+      hipGraph_t tmp = nullptr;
+      (void)hipStreamEndCapture(stream, &tmp);
+      if (tmp) (void)hipGraphDestroy(tmp);
+      throw;
+    }
+    HIPCHK(hipStreamEndCapture(stream, &g));
+    const hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    HIPCHK(ie);
+    if (graph_cache.size() >= kGraphCacheMax) {
+      (void)hipGraphExecDestroy(graph_cache.front().second);
+      graph_cache.erase(graph_cache.begin());
+    }
+    graph_cache.emplace_back(sig, exec);
+    return exec;
   }
 
   void decode_steps(int n) {
     if (!have_prefill) fail("decode: no prefill state");
     if (n <= 0) return;
-    if (!opts.use_graph || prof) {
-      for (int i = 0; i < n; ++i) enqueue_decode_step();
-      HIPCHK(hipGetLastError());
-      if (xcd_sync.p) tap("xcd_sync", xcd_sync.p, 2 * 8 * 64 * 4);
-      return;
+    const bool eager = !opts.use_graph || prof;
+    const int kps = dattn_keys_per_split(kv_f32());
+    for (int i = 0; i < n; ++i) {
+      // this step feeds the token at position <= pos_hi_ and attends keys 0 .. pos_hi_
+      live_nsplit_ = uses_key_splits() ? std::min(attn_nsplit, pos_hi_ / kps + 1) : attn_nsplit;
+      if (eager) enqueue_decode_step();
+      else HIPCHK(hipGraphLaunch(graph_for_step(), stream));
+      ++pos_hi_;
     }
-    std::string sig = make_graph_sig();
-    if (!graph_exec || sig != graph_sig) {
-      if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
-      hipGraph_t g = nullptr;
-      HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-      try {
-        enqueue_decode_step();
-      } catch (...) {
-        hipGraph_t tmp = nullptr;
-        (void)hipStreamEndCapture(stream, &tmp);
-        if (tmp) (void)hipGraphDestroy(tmp);
-        throw;
-      }
-      HIPCHK(hipStreamEndCapture(stream, &g));
-      HIPCHK(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(g);
-      graph_sig = sig;
-    }
-    for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(graph_exec, stream));
+    if (eager) HIPCHK(hipGetLastError());
     if (xcd_sync.p) tap("xcd_sync", xcd_sync.p, 2 * 8 * 64 * 4);  // (debug_taps only) counters + placement diagnostics of the fused launch
   }
 
@@ -1022,7 +1048,7 @@ struct q3a_engine {
   bool head_logits_ = true;  // store the logits of a batched decode step (step API, debug taps); off inside run_resident
 
   ~q3a_engine() {
-    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    for (auto& ge : graph_cache) (void)hipGraphExecDestroy(ge.second);
     for (auto cs : chain_streams) (void)hipStreamDestroy(cs);
     for (auto ce : join_ev) (void)hipEventDestroy(ce);
     if (fork_ev) (void)hipEventDestroy(fork_ev);
@@ -1320,7 +1346,7 @@ int32_t q3a_profile_decode_step(q3a_engine* e, q3a_kernel_profile* out) {
   std::vector<ProfEvent> evs;
   e->prof = &evs;
   try {
-    e->enqueue_decode_step();
+    e->decode_steps(1);  // eager while `prof` is set: every launch between a pair of events
     HIPCHK(hipStreamSynchronize(e->stream));
   } catch (...) {
     e->prof = nullptr;

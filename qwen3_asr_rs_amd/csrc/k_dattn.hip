@@ -699,7 +699,9 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restri
 
 const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s) {
   if (S <= 0) return nullptr;
-  if (a.nsplit <= 0 || a.nsplit * dattn_keys_per_split(kv_f32) < a.max_ctx) return "decode_attn: nsplit does not cover max_ctx";
+  // the caller launches as many splits as the caches HOLD keys for (every pos < nsplit * keys per split), not as many as they
+  // have room for: keys beyond the last split are never looked at
+  if (a.nsplit <= 0 || (a.nsplit - 1) * dattn_keys_per_split(kv_f32) >= a.max_ctx) return "decode_attn: 1 .. ceil(max_ctx / keys per split) key splits";
   const int group = a.n_q / a.n_kv;
   dim3 grid(a.n_kv, S, a.nsplit), block(DA_WAVES * 64);
 #define Q3A_DA(G)                                                                                   \
@@ -719,7 +721,7 @@ const char* launch_qkv_attn(const DecodeAttnArgs& a, const QkvFuseArgs& fa, bool
   const int group = a.n_q / a.n_kv;
   if (a.n_kv != 8 || group != 2) return "qkv_attn: 8 kv heads with 2 query heads each (one kv head per XCD)";
   if (fa.K != 1024 && fa.K != 2048) return "qkv_attn: hidden size 1024 or 2048";
-  if (a.nsplit <= 0 || a.nsplit > 32 || a.nsplit * dattn_keys_per_split(kv_f32) < a.max_ctx) return "qkv_attn: 1..32 key splits covering max_ctx";
+  if (a.nsplit <= 0 || a.nsplit > 32 || (a.nsplit - 1) * dattn_keys_per_split(kv_f32) >= a.max_ctx) return "qkv_attn: 1..32 key splits inside max_ctx";
   if (!fa.sync || !fa.rms_w || fa.qkv_out != a.qkv) return "qkv_attn: sync words, norm weight and the shared qkv row are required";
   QkvFuse f{fa.x, fa.rms_w, fa.eps, fa.W, fa.bias, fa.K, fa.qkv_out, fa.sync, fa.debug};
   const dim3 grid(256), block(DA_WAVES * 64);

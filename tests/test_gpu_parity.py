@@ -147,6 +147,32 @@ def test_batch_above_gemv_path(tiny_dir):
     _stage_check(tiny_dir, clips, True, steps=3)
 
 
+def test_key_splits_follow_the_context_not_the_capacity(tiny_dir):
+    """The one-sequence decode attention launches as many 128-key splits as the caches HOLD keys for (longest prompt + steps
+    so far), whatever max_new_tokens reserves: a 40-token prompt generating 230 tokens crosses the 128- and 256-key marks, so
+    the loop replays three different graphs (split count 1, 2, 3) out of the engine's graph cache.  Precise mode: exact ids
+    against the oracle, graph replay and eager, 1 / 2 sequences (GEMV path) and 5 (skinny path + split attention + merge
+    launch); default mode: graph == eager; a second batch of the same shape re-uses the cached graphs."""
+    steps = 230
+    clips = [synthetic.synthetic_clip(500 + i, 1.6 + 0.3 * i) for i in range(5)]
+    orc = O.AsrOracle(tiny_dir)
+    want = [orc.transcribe_ids(c, fixed_new_tokens=steps).all_step_ids[:steps] for c in clips]
+    for B in (1, 2, 5):
+        for graph in (True, False):
+            eng = HipEngine(tiny_dir, 0, precise=True, use_graph=graph, max_new_tokens=512)   # capacity 768 keys: 6 splits
+            got = eng.transcribe_batch(clips[:B], None, max_new=steps, fixed_new_tokens=steps)
+            assert got == want[:B], (B, graph)
+            if graph:
+                assert eng.transcribe_batch(clips[:B], None, max_new=steps, fixed_new_tokens=steps) == want[:B]
+            eng.close()
+    out = []
+    for graph in (True, False):
+        eng = HipEngine(tiny_dir, 0, use_graph=graph, max_new_tokens=512)
+        out.append(eng.transcribe_batch(clips[:2], None, max_new=steps, fixed_new_tokens=steps))
+        eng.close()
+    assert out[0] == out[1]
+
+
 def test_batched_head_argmax_in_the_gemm_epilogue(tiny_dir):
     """Default mode, 3..32 sequences: the lm_head GEMM writes one argmax partial per 64-column tile and row, and inside
     transcribe_batch the logits are not stored at all.  The ids of transcribe_batch, the ids of the step API and the argmax
