@@ -246,7 +246,10 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *   "fuse_qkv_attn"      0 (default) / 1: one-sequence decode runs the qkv projection and the attention key splits as ONE launch
  *                        handed over inside each XCD (8 kv heads x 2 query heads only); taken at the next prefill.
  *   "eos_run_ahead"      decode steps the natural-EOS greedy loop keeps enqueued ahead of the device (default 2): the stop
- *                        condition is evaluated on the device and read from pinned host memory without synchronising. */
+ *                        condition is evaluated on the device and read from pinned host memory without synchronising.
+ *   "live_key_splits"    1 (default): the one-sequence decode attention launches as many 128-key splits as the caches HOLD keys
+ *                        for (longest prompt + steps so far; the count is part of the graph signature), so max_new_tokens is a
+ *                        capacity, not a cost; 0: as many as the caches have room for. */
 int32_t q3a_debug_set(const char* key, int32_t value);
 
 /* Kernel self-tests against naive device references (no model needed): returns max abs error. */

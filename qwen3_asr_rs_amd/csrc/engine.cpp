@@ -109,6 +109,7 @@ Knobs& knobs() {
     env("Q3A_SKINNY_Q", k.skinny_q);
     env("Q3A_FUSE_QKV_ATTN", k.fuse_qkv_attn);
     env("Q3A_EOS_RUN_AHEAD", k.eos_run_ahead);
+    env("Q3A_LIVE_KEY_SPLITS", k.live_key_splits);
   });
   return k;
 }
@@ -937,7 +938,7 @@ struct q3a_engine {
     const int kps = dattn_keys_per_split(kv_f32());
     for (int i = 0; i < n; ++i) {
       // this step feeds the token at position <= pos_hi_ and attends keys 0 .. pos_hi_
-      live_nsplit_ = uses_key_splits() ? std::min(attn_nsplit, pos_hi_ / kps + 1) : attn_nsplit;
+      live_nsplit_ = (uses_key_splits() && knobs().live_key_splits.load() != 0) ? std::min(attn_nsplit, pos_hi_ / kps + 1) : attn_nsplit;
       if (eager) enqueue_decode_step();
       else HIPCHK(hipGraphLaunch(graph_for_step(), stream));
       ++pos_hi_;
@@ -1460,6 +1461,7 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (strcmp(key, "skinny_q") == 0) { kn.skinny_q = value; return 0; }
   if (strcmp(key, "fuse_qkv_attn") == 0) { kn.fuse_qkv_attn = value; return 0; }
   if (strcmp(key, "eos_run_ahead") == 0) { kn.eos_run_ahead = value; return 0; }
+  if (strcmp(key, "live_key_splits") == 0) { kn.live_key_splits = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";
   return 1;
 }
