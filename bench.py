@@ -319,6 +319,42 @@ def launch_check(args):
         dist.destroy_process_group()
 
 
+def two_streams_leg(model_dir, clips, new_tokens, precise, batches=6):
+    """NOT the headline (that is one engine, one batch at a time): two engines on the ONE GPU sharing one weight arena, one
+    host thread each (the C ABI releases the GIL), the same batch alternately -- while one engine decodes (latency / HBM
+    bound) the other's mel + encoder + prefill (MFMA bound) and decode launches fill its gaps.  Each engine still runs the
+    named batch size; per-request latency rises, requests per second rise more.  Host-to-host (PCM upload inside the clock)."""
+    import threading
+    from qwen3_asr_rs_amd.distributed import pack_arena_host
+    from qwen3_asr_rs_amd.engine import HipEngine
+    arena = pack_arena_host(model_dir).to("cuda:0")
+    torch.cuda.synchronize()
+    engs = [HipEngine(model_dir, 0, precise=precise, max_new_tokens=max(new_tokens, 16), device_arena=(arena.data_ptr(), arena.numel()))
+            for _ in range(2)]
+    seconds = sum(len(c) for c in clips) / 16000.0
+
+    def run(eng, n, out):
+        for _ in range(n):
+            out.append(eng.transcribe_batch(clips, None, max_new=new_tokens, fixed_new_tokens=new_tokens))
+
+    for e in engs:
+        run(e, 1, [])
+    torch.cuda.synchronize()
+    ref = []
+    t0 = time.perf_counter(); run(engs[0], batches, ref); torch.cuda.synchronize(); one = (time.perf_counter() - t0) / batches
+    outs = [[], []]
+    th = [threading.Thread(target=run, args=(engs[i], batches // 2, outs[i])) for i in range(2)]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    torch.cuda.synchronize(); two = (time.perf_counter() - t0) / (2 * (batches // 2))
+    same = all(x == ref[0] for x in outs[0] + outs[1])
+    for e in engs: e.close()
+    return {"workload": f"two engines on one GPU sharing the weight arena, batch={len(clips)} each, {2 * (batches // 2)} batches alternating "
+                        "(host to host)", "value": round(seconds / two, 3), "unit": "audio-seconds/sec", "ms_per_batch": round(two * 1e3, 3),
+            "one_engine": {"value": round(seconds / one, 3), "ms_per_batch": round(one * 1e3, 3)}, "ids_equal_to_one_engine": same}
+
+
 def config4_leg(dist, dev, rank, world, local_rank, seconds, new_tokens, steps, warmup, precise):
     """BASELINE configs[4] scaled to this N: Qwen3-ASR-1.7B, 32 clips per GPU, weights packed on rank 0 and shipped with one
     RCCL broadcast of the arena; all ranks time the same window (barrier + max over ranks)."""
@@ -609,6 +645,11 @@ def main():
                                                      elapsed / args.steps * 1e3)
             except Exception as ex:  # noqa: BLE001
                 out["natural_eos"] = {"value": None, "error": str(ex)[:300]}
+        if world == 1 and not args.no_extra and B == 1:
+            try:
+                out["two_streams"] = two_streams_leg(model_dir, clips, args.new_tokens, args.precise)
+            except Exception as ex:  # noqa: BLE001
+                out["two_streams"] = {"value": None, "error": str(ex)[:300]}
         if world == 1 and not args.no_extra and args.preset == "0.6b" and B == 1:
             extra = []
             for preset, b in (("0.6b", 32), ("1.7b", 16)):

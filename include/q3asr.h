@@ -249,7 +249,11 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *                        condition is evaluated on the device and read from pinned host memory without synchronising.
  *   "live_key_splits"    1 (default): the one-sequence decode attention launches as many 128-key splits as the caches HOLD keys
  *                        for (longest prompt + steps so far; the count is part of the graph signature), so max_new_tokens is a
- *                        capacity, not a cost; 0: as many as the caches have room for. */
+ *                        capacity, not a cost; 0: as many as the caches have room for.
+ *   "gemm16_ring"        0 (default): the small-M GEMMs of a one-clip encoder / prefill stage K tiles through two LDS buffers; 1: rings
+ *                        of 3-4 stages with counted vmcnt (encoder + prefill of a 30 s clip 4.1 -> 3.8 ms).  Off by default: with
+ *                        SEVERAL engines busy on one GPU the ring raised the rate of a rare run-to-run difference in the prefill
+ *                        (DESIGN.md section 8); alone on the GPU both forms are bit-reproducible. */
 int32_t q3a_debug_set(const char* key, int32_t value);
 
 /* Kernel self-tests against naive device references (no model needed): returns max abs error. */

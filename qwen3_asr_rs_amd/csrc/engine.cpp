@@ -110,6 +110,7 @@ Knobs& knobs() {
     env("Q3A_FUSE_QKV_ATTN", k.fuse_qkv_attn);
     env("Q3A_EOS_RUN_AHEAD", k.eos_run_ahead);
     env("Q3A_LIVE_KEY_SPLITS", k.live_key_splits);
+    env("Q3A_GEMM16_RING", k.gemm16_ring);
   });
   return k;
 }
@@ -677,25 +678,43 @@ struct q3a_engine {
         KCHK(launch_qknorm_rope_kv(rk, total_P, kv_f32(), stream));
       }
       at.k = kc_layer(li); at.v = vc_layer(li);
+      // (debug_taps + Q3A_DEBUG_LAYER_TAPS=1: raw copies of every prefill layer's intermediate buffers, for bisecting a
+      // run-to-run difference to one launch -- tools/bisect_layers.py)
+      static const bool layer_taps = [] { const char* e = getenv("Q3A_DEBUG_LAYER_TAPS"); return e && atoi(e) != 0; }();
+      auto ltap = [&](const char* what, const void* ptr, size_t bytes) {
+        if (!layer_taps || !opts.debug_taps) return;
+        char name[32];
+        snprintf(name, sizeof(name), "L%02d_%s", li, what);
+        tap(name, ptr, bytes);
+      };
+      const size_t act_b = sp ? 4 : 2;  // bytes per activation element (bf16 in the default mode)
+      if (fuse_rope) ltap("qkvs", dec_qkv.p, std::min((size_t)1024, (size_t)total_P) * QKV * 4);  // fp32 scratch of the trailing rows (small GEMM -> separate rope kernel)
+      ltap("k", kc_layer(li), (size_t)B * d.n_kv * max_ctx * 128 * kv_elem());
+      ltap("v", vc_layer(li), (size_t)B * d.n_kv * max_ctx * 128 * kv_elem());
       if (valu_attn) {
         KCHK(launch_attn_prefill(at, d.n_q / d.n_kv, kv_f32(), stream));
         if (!sp) KCHK(launch_to_bf16(dec_ctx.as<float>(), dec_ctx16.as<uint16_t>(), (size_t)total_P * QD, stream));
       } else {
         KCHK(launch_fattn_prefill(at, d.n_q / d.n_kv, stream));
       }
+      ltap("attn", ctx_in.p, (size_t)total_P * QD * act_b);
       {
         GemmEpilogue ep; ep.out = dec_x.as<float>(); ep.ldo = H; ep.resid = dec_x.as<float>(); ep.bias = o_bias ? wf(l.o_b) : nullptr;
         act_gemm(ctx_in, QD, wh(l.o_w), total_P, H, QD, ep, false);
       }
+      ltap("o", dec_x.p, (size_t)total_P * H * 4);
       KCHK(launch_rmsnorm(dec_x.as<float>(), wf(l.post_ln), dec_ln.as<float>(), total_P, H, d.rms_eps, stream, act16(dec_ln)));
+      ltap("ln2", dec_ln.p, (size_t)total_P * H * act_b);
       {
         GemmEpilogue ep; act_out(ep, dec_act); ep.ldo = I; ep.bias = mlp_bias ? wf(l.gu_b) : nullptr;
         act_gemm(dec_ln, H, wh(l.gu_w), total_P, 2 * I, H, ep, true);
       }
+      ltap("act", dec_act.p, (size_t)total_P * I * act_b);
       {
         GemmEpilogue ep; ep.out = dec_x.as<float>(); ep.ldo = H; ep.resid = dec_x.as<float>(); ep.bias = mlp_bias ? wf(l.down_b) : nullptr;
         act_gemm(dec_act, I, wh(l.down_w), total_P, H, I, ep, false);
       }
+      ltap("x", dec_x.p, (size_t)total_P * H * 4);
       if (li == 0) tap("dec_layer0", dec_x.p, (size_t)total_P * H * 4);
     }
     // only the last row of every sequence feeds the lm_head (the reference computes all rows and keeps
@@ -1462,6 +1481,7 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (strcmp(key, "fuse_qkv_attn") == 0) { kn.fuse_qkv_attn = value; return 0; }
   if (strcmp(key, "eos_run_ahead") == 0) { kn.eos_run_ahead = value; return 0; }
   if (strcmp(key, "live_key_splits") == 0) { kn.live_key_splits = value; return 0; }
+  if (strcmp(key, "gemm16_ring") == 0) { kn.gemm16_ring = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";
   return 1;
 }

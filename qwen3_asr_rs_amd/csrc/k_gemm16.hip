@@ -567,12 +567,12 @@ __global__ __launch_bounds__(256) void gemm16k_kernel(ALoader A, const uint16_t*
 template <int BM, int BN, int BK, bool GLU, class ALoader>
 void launch16(const ALoader& A, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  // Dense operands, BK = 64, tiles up to 64x64: a ring of LDS stages as deep as still lets every workgroup of the launch be
-  // resident at once (64x64: 16 KiB per stage, 160 KiB per CU) -- four stages up to 2 workgroups per CU, three up to 3;
-  // beyond that (e.g. the lm_head of a batched decode step, 2374 workgroups) residency is worth more than depth: two.
-  // A/B knob: Q3A_GEMM16_STAGES=2 keeps two everywhere.
+  // Dense operands, BK = 64, tiles up to 64x64, knob "gemm16_ring" (Q3A_GEMM16_RING=1; default OFF): a ring of
+  // LDS stages as deep as still lets every workgroup of the launch be resident at once (64x64: 16 KiB per stage, 160 KiB per
+  // CU) -- four stages up to 2 workgroups per CU, three up to 3; beyond that (e.g. the lm_head of a batched decode step,
+  // 2374 workgroups) residency is worth more than depth: two.
   constexpr bool ring = std::is_same<ALoader, DenseA16>::value && BK == 64 && BM <= 64 && BN <= 64;
-  static const bool two_stage = [] { const char* e = getenv("Q3A_GEMM16_STAGES"); return e && atoi(e) == 2; }();
+  const bool two_stage = knobs().gemm16_ring.load() == 0;
   if constexpr (ring) {
     if (!two_stage && tiles <= 512) {
       hipLaunchKernelGGL((gemm16_kernel<BM, BN, BK, GLU, ALoader, 4>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
@@ -644,8 +644,8 @@ const char* launch_gemm16_small(const uint16_t* X, int lda, const uint16_t* W, i
     const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
     // K steps of 256 in two stages (32 KiB in flight per workgroup); where 256 does not divide K (the encoder's d_model 896)
     // steps of 128 in a ring of four stages (48 KiB in flight) instead of two (16 KiB): 6.5 vs 7.9 us on enc out.  The ring
-    // measured no gain over the 256-steps (profiles/r3_phase_probe_one_clip_gemms.txt).  A/B knob Q3A_GEMM16_STAGES=2.
-    static const bool two_stage = [] { const char* e = getenv("Q3A_GEMM16_STAGES"); return e && atoi(e) == 2; }();
+    // measured no gain over the 256-steps (profiles/r3_phase_probe_one_clip_gemms.txt).  Knob "gemm16_ring" (default off).
+    const bool two_stage = knobs().gemm16_ring.load() == 0;
     // (Measured and dropped: 32x64 tiles, at most one per CU, ring of four 128-steps -- the launch then moves 96 instead of
     // 2 x 64 operand rows per K step on its busiest CUs, but 48-74 CUs idle: 926 vs 930 us over the 92 launches of a clip.
     // These launches run at ~75 GB/s of LDS-DMA per CU whatever the tile, profiles/r3_phase_probe_one_clip_gemms.txt.)

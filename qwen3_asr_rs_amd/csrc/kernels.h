@@ -64,6 +64,7 @@ struct Knobs {
   std::atomic<int> skinny_q{1};                 // Q3A_SKINNY_Q: quarter workgroups for the o / down projections
   std::atomic<int> fuse_qkv_attn{0};            // Q3A_FUSE_QKV_ATTN: one-sequence decode qkv projection + attention in one launch
   std::atomic<int> eos_run_ahead{2};            // Q3A_EOS_RUN_AHEAD: decode steps kept enqueued ahead of the device in natural-EOS mode
+  std::atomic<int> gemm16_ring{0};              // Q3A_GEMM16_RING: 3-4-stage LDS rings with counted vmcnt in the small-M GEMMs (default: two stages)
   std::atomic<int> live_key_splits{1};          // Q3A_LIVE_KEY_SPLITS: one-sequence decode attention launches the key splits the caches HOLD keys for (0: as many as they have room for)
 };
 Knobs& knobs();
