@@ -151,6 +151,7 @@ struct q3a_engine {
   DevBuf x_dec, d_pos, next_tok, out_ids, step_count, done, s_ln, s_qkv, s_ctx, s_act, logits, forced_tok, part_val, part_idx;
   DevBuf attn_pm, attn_pl, attn_po;
   DevBuf nn_x, nn_ss;  // pre-normalised residual row for the next skinny GEMM: [32 * hidden] bf16 fragment order, [hidden/16][32] f32
+  DevBuf dbg_scratch;  // (debug) RopeKvArgs::dbg_scratch_copy
   DevBuf rope_cur;  // [B][128] cos|sin row of each sequence's current position (kept by argmax_finalize for decode attention)
   DevBuf enc_ctx16, dec_ctx16;  // opts.valu_attention in the default mode: bf16 copy of the fp32 attention context
   DevBuf dec_q16;
@@ -681,6 +682,8 @@ struct q3a_engine {
       // (debug_taps + Q3A_DEBUG_LAYER_TAPS=1: raw copies of every prefill layer's intermediate buffers, for bisecting a
       // run-to-run difference to one launch -- tools/bisect_layers.py)
       static const bool layer_taps = [] { const char* e = getenv("Q3A_DEBUG_LAYER_TAPS"); return e && atoi(e) != 0; }();
+      static const bool scratch_copy = [] { const char* e = getenv("Q3A_DEBUG_SCRATCH_COPY"); return e && atoi(e) != 0; }();
+      if (layer_taps && scratch_copy && opts.debug_taps) { dbg_scratch.ensure((size_t)1024 * QKV * 4); rk.dbg_scratch_copy = dbg_scratch.p; }
       auto ltap = [&](const char* what, const void* ptr, size_t bytes) {
         if (!layer_taps || !opts.debug_taps) return;
         char name[32];
@@ -688,7 +691,10 @@ struct q3a_engine {
         tap(name, ptr, bytes);
       };
       const size_t act_b = sp ? 4 : 2;  // bytes per activation element (bf16 in the default mode)
-      if (fuse_rope) ltap("qkvs", dec_qkv.p, std::min((size_t)1024, (size_t)total_P) * QKV * 4);  // fp32 scratch of the trailing rows (small GEMM -> separate rope kernel)
+      if (fuse_rope) {
+        ltap("qkvs", dec_qkv.p, std::min((size_t)1024, (size_t)total_P) * QKV * 4);  // fp32 scratch of the trailing rows (small GEMM -> separate rope kernel)
+        if (rk.dbg_scratch_copy) ltap("qkvm", rk.dbg_scratch_copy, std::min((size_t)1024, (size_t)total_P) * QKV * 4);  // the same, copied BETWEEN the two launches
+      }
       ltap("k", kc_layer(li), (size_t)B * d.n_kv * max_ctx * 128 * kv_elem());
       ltap("v", vc_layer(li), (size_t)B * d.n_kv * max_ctx * 128 * kv_elem());
       if (valu_attn) {

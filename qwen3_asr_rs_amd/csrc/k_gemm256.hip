@@ -622,6 +622,7 @@ const char* launch_gemm256_qkrope(const uint16_t* X, int lda, const uint16_t* W,
     GemmEpilogue e2;
     e2.out = rk.qkv; e2.ldo = N; e2.bias = bias;  // rk.qkv: fp32 scratch [>= M - M1][N]
     if (const char* err = launch_gemm16_small(X + (size_t)M1 * lda, lda, W, M - M1, N, K, e2, false, s)) return err;
+    if (rk.dbg_scratch_copy) (void)hipMemcpyAsync(rk.dbg_scratch_copy, rk.qkv, (size_t)(M - M1) * N * 4, hipMemcpyDeviceToDevice, s);  // (bisect_layers.py)
     RopeKvArgs r2 = rk;
     r2.row_seq += M1; r2.row_pos += M1; r2.q16 += (size_t)M1 * rk.n_q * 128;
     return launch_qknorm_rope_kv(r2, M - M1, false, s);

@@ -146,6 +146,8 @@ struct RopeKvArgs {
   int n_q, n_kv, max_ctx;
   uint16_t* q16;            // non-null (default mode, MFMA attention): q is written HERE as bf16 [rows][n_q*128] -- the value the
                             // attention kernel rounds it to on load anyway -- instead of in place as fp32 (half the bytes twice)
+  void* dbg_scratch_copy = nullptr;  // debug (Q3A_DEBUG_LAYER_TAPS + Q3A_DEBUG_SCRATCH_COPY): launch_gemm256_qkrope copies the trailing rows'
+                                     // fp32 scratch here BETWEEN the small GEMM and the rope kernel
 };
 const char* launch_qknorm_rope_kv(const RopeKvArgs& a, int rows, bool kv_f32, hipStream_t s);
 // qkv projection (bf16 X [M][K] . W[(n_q + 2 n_kv) * 128][K]^T + bias) with the kernel above as its epilogue: q -> a.q16, k / v

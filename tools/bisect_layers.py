@@ -15,7 +15,7 @@ clips = [synthetic.synthetic_clip(i, 30.0) for i in range(B)]
 arena = pack_arena_host(d).to("cuda:0"); torch.cuda.synchronize()
 A = HipEngine(d, 0, max_new_tokens=16, debug_taps=True, device_arena=(arena.data_ptr(), arena.numel()))
 Bg = HipEngine(d, 0, max_new_tokens=100, device_arena=(arena.data_ptr(), arena.numel()))
-ORDER = [f"L{li:02d}_{w}" for li in range(28) for w in ("qkvs", "k", "v", "attn", "o", "ln2", "act", "x")]
+ORDER = [f"L{li:02d}_{w}" for li in range(28) for w in (("qkvm",) if os.environ.get("Q3A_DEBUG_SCRATCH_COPY") else ()) + ("qkvs", "k", "v", "attn", "o", "ln2", "act", "x")]
 def run(): return A.transcribe_batch(clips, None, max_new=2, fixed_new_tokens=2)
 run()
 ref_last = A.debug_read("dec_last_hidden").copy()
@@ -38,12 +38,12 @@ for it in range(RUNS):
             ne = ne.reshape(-1, MAXCTX, 256).copy()
             ne[:, P:, :] = False
             ne = ne.reshape(-1)
-        if k.endswith("_qkvs"):  # only the rows the trailing GEMM writes (672 at 32 x 405 prompt rows)
+        if k.endswith(("_qkvs", "_qkvm")):  # only the rows the trailing GEMM writes (672 at 32 x 405 prompt rows)
             ne = ne.reshape(-1, 4096 * 4).copy(); ne[672:, :] = False; ne = ne.reshape(-1)
         if ne.any():
             idx = np.nonzero(ne)[0]
-            esz = 4 if k.endswith(("_o", "_x", "_qkvs")) else 2
-            cols = {"qkvs": 4096, "k": 128, "v": 128, "attn": 2048, "o": 1024, "ln2": 1024, "act": 3072, "x": 1024}[k.split("_")[1]]
+            esz = 4 if k.endswith(("_o", "_x", "_qkvs", "_qkvm")) else 2
+            cols = {"qkvm": 4096, "qkvs": 4096, "k": 128, "v": 128, "attn": 2048, "o": 1024, "ln2": 1024, "act": 3072, "x": 1024}[k.split("_")[1]]
             el = np.unique(idx // esz)
             rows, cs = el // cols, el % cols
             print(f"   first differing buffer {k}: {len(el)} elements; rows {rows.min()}..{rows.max()} ({len(np.unique(rows))} distinct), cols {cs.min()}..{cs.max()} ({len(np.unique(cs))} distinct)", flush=True)
@@ -56,7 +56,7 @@ for it in range(RUNS):
                 print(f"      row {r0} cols 104..127 now : {np.array2string(a_[104:128], precision=4, max_line_width=250)}", flush=True)
                 print(f"      row {r0} cols 104..127 ref : {np.array2string(b_[104:128], precision=4, max_line_width=250)}", flush=True)
                 print(f"      row {r0} cols  40.. 63 equal: {bool((a_[40:64] == b_[40:64]).all())}; |row| {np.linalg.norm(b_):.3f}", flush=True)
-            if not k.endswith("_qkvs"): break
+            if not k.endswith(("_qkvs", "_qkvm")): break
     if events >= 3: break
 stop = True; th.join()
 print(f"{events} event(s) in {it + 1} runs", flush=True)
