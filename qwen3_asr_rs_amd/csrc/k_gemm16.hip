@@ -13,8 +13,8 @@
 //     (2 x 2), each wave (BM/32) x (BN/32) fragments of v_mfma_f32_16x16x32_bf16;
 //   * K loop, two LDS buffers: one barrier per K tile (its workgroup release carries the vmcnt(0) that lands the
 //     LDS-DMA issued one iteration earlier), then the next tile's loads are issued and fly under this tile's MFMAs;
-//   * NS = 3 / 4 (64x64 / 32x64 tiles of dense operands, launches of up to 768 / 512 workgroups): a ring of LDS stages
-//     with two / three K tiles in flight and a COUNTED vmcnt in front of a raw s_barrier.  With two stages a K step costs
+//   * knob "gemm16_ring" (off by default): NS = 3 / 4 (64x64 / 32x64 tiles of dense operands, launches of
+//     up to 768 / 512 workgroups): a ring of LDS stages with two / three K tiles in flight and a COUNTED vmcnt in front of a raw s_barrier.  With two stages a K step costs
 //     one full L2 round trip for eight MFMAs per wave: on the one-clip shapes (M ~ 400: 300-700 workgroups, 14-16 K steps)
 //     the K loop took 9-10.5 us per workgroup, 4.9-5.9 us through the ring (profiles/r3_phase_probe_one_clip_gemms.txt);
 //   * the W fragment is the FIRST MFMA operand: the accumulator holds the transposed tile, a lane owns four consecutive
