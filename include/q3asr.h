@@ -250,10 +250,15 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *   "live_key_splits"    1 (default): the one-sequence decode attention launches as many 128-key splits as the caches HOLD keys
  *                        for (longest prompt + steps so far; the count is part of the graph signature), so max_new_tokens is a
  *                        capacity, not a cost; 0: as many as the caches have room for.
- *   "gemm16_ring"        0 (default): the small-M GEMMs of a one-clip encoder / prefill stage K tiles through two LDS buffers; 1: rings
- *                        of 3-4 stages with counted vmcnt (encoder + prefill of a 30 s clip 4.1 -> 3.8 ms).  Off by default: with
- *                        SEVERAL engines busy on one GPU the ring raised the rate of a rare run-to-run difference in the prefill
- *                        (DESIGN.md section 8); alone on the GPU both forms are bit-reproducible. */
+ *   "gemm16_ring"        1 (default since round 4): the small-M GEMMs of a one-clip encoder / prefill stage K tiles through rings
+ *                        of 3-4 LDS stages with counted vmcnt (encoder + prefill of a 30 s clip 4.1 -> 3.8 ms); 0: two LDS buffers,
+ *                        one barrier per K tile.  (Round 3 kept this off because it raised the rate of a rare run-to-run difference
+ *                        with several engines busy on one GPU; that was the packed-fp32 op_sel hazard of csrc/dev.h, which the
+ *                        library no longer contains -- DESIGN.md section 8.)
+ *   "rope_variant"       hazard-isolation builds only (-DQ3A_ROPE_EXPERIMENT, never the product library): arithmetic form of
+ *                        qknorm_rope_kv_kernel (csrc/dev.h head_norm_rope; tools/soak_engines.py).  Ignored by the product library.
+ *   "rope_twice"         debug, 0 (default) / 1: batch-sized prefills execute the trailing rows' rope kernel a second time into
+ *                        shadow buffers and compare (q3a_debug_read "rope_twice_log": 64 B of counters + 3584-byte records). */
 int32_t q3a_debug_set(const char* key, int32_t value);
 
 /* Kernel self-tests against naive device references (no model needed): returns max abs error. */

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -27,7 +28,10 @@ SOURCES = ["engine.cpp", "model.cpp", "k_gemm.hip", "k_mel.hip", "k_conv1.hip", 
 HEADERS = ["dev.h", "kernels.h", "model.h", "json.h", "host.h", "ops.h", "unicode_tables.h", os.path.join("..", "..", "include", "q3asr.h"),
            os.path.join("..", "..", "include", "q3asr_ops.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+# -fno-slp-vectorize: hipcc's SLP vectoriser packs scalar fp32 code into v_pk_*_f32 with op_sel operand swaps, and a packed fp32
+# instruction whose low half reads a high register is unsafe on gfx950 while a second queue is busy (csrc/dev.h, DESIGN.md
+# section 8); with the pass off, packed fp32 only comes from explicit f32x2_t code, and scan_isa() below checks what was emitted.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 # A/B builds for kernel experiments: Q3A_BUILD_VARIANT=name Q3A_BUILD_DEFINES="-DX=1 ..." builds
 # lib/libq3asr_hip_<name>.so next to the product library (load it with Q3A_LIB=<path>, see _lib.py).
@@ -55,7 +59,8 @@ def _compile(src: str, hdr_hash: str, force: bool) -> str:
     want = _hash([spath]) + hdr_hash
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == want:
         return obj
-    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", spath, "-o", obj]
+    # -save-temps=obj keeps the device assembly (<stem>-hip-amdgcn-amd-amdhsa-gfx950.s) next to the object for scan_isa()
+    cmd = [HIPCC] + FLAGS + (["-x", "hip", "-save-temps=obj"] if src.endswith(".hip") else []) + ["-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -66,12 +71,47 @@ def _compile(src: str, hdr_hash: str, force: bool) -> str:
     return obj
 
 
+_LABEL = re.compile(r"^([A-Za-z_][\w$]*):")
+_PK_F32 = re.compile(r"^\s*(v_pk_(?:mul|fma|add)_f32)\b.*\bop_sel:\[([01,]+)\]")
+
+
+def isa_path(src: str) -> str:
+    """Device assembly hipcc kept for a .hip source of the product build (build/q3asr/<stem>-hip-amdgcn-amd-amdhsa-gfx950.s)."""
+    return os.path.join(OBJ_DIR, os.path.splitext(src)[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def scan_isa(paths=None):
+    """Packed fp32 instructions with an op_sel bit set (low result half reading a HIGH source register), per kernel.
+
+    That form returned wrong low halves in lanes 48-63 on gfx950 while a second queue kept the GPU busy (csrc/dev.h,
+    profiles/r4_pk_op_sel_hazard.txt).  Returns [(file, kernel, instruction line)]; build() refuses a library that has any."""
+    if paths is None:
+        paths = [isa_path(s) for s in SOURCES if s.endswith(".hip")]
+    found = []
+    for path in paths:
+        kernel = "?"
+        with open(path) as f:
+            for line in f:
+                lm = _LABEL.match(line)
+                if lm:
+                    kernel = lm.group(1)
+                m = _PK_F32.match(line)
+                if m and "1" in m.group(2):
+                    found.append((os.path.basename(path), kernel, line.strip()))
+    return found
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     hdr_hash = _hash([os.path.join(CSRC, h) for h in HEADERS])
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(lambda s: _compile(s, hdr_hash, force), SOURCES))
+    hazards = scan_isa()
+    if hazards and os.environ.get("Q3A_ALLOW_ISA_HAZARD", "0") in ("", "0"):
+        lines = "\n".join(f"  {f}: {k}: {i}" for f, k, i in hazards[:20])
+        raise RuntimeError(f"{len(hazards)} packed fp32 instruction(s) with an op_sel bit set in the device code (csrc/dev.h: unsafe on gfx950; "
+                           f"Q3A_ALLOW_ISA_HAZARD=1 builds experiment variants anyway):\n{lines}")
     link_stamp = LIB_PATH + ".stamp"
     want = _hash(objs)
     if force or not os.path.exists(LIB_PATH) or not os.path.exists(link_stamp) or open(link_stamp).read() != want:

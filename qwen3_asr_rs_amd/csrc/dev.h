@@ -153,17 +153,81 @@ __device__ __forceinline__ float lane_bcast(float v, int lane_uniform) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
 }
 
+// ---- gfx950 hazard: packed fp32 with op_sel (profiles/r4_pk_op_sel_hazard.txt) ---------------------------
+// A v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 whose LOW result half reads the HIGH register of a source pair (an `op_sel:[..1..]`
+// modifier: the operand swap / high-register broadcast hipcc emits for scalar code it SLP-packs, or for {x, x} splats of the second
+// register of a 64-bit load) occasionally returns that half as if the product were 0, in lanes 48-63 only, while a second HIP queue
+// keeps the GPU busy -- reproduced with a hand-written instruction (the same multiply with the operands swapped in registers and
+// no op_sel never fails; tools/soak_engines.py + the Q3A_ROPE_EXPERIMENT variants below).  Consequences for this library:
+//   * it is built with -fno-slp-vectorize (qwen3_asr_rs_amd/build.py), so packed fp32 only comes from explicit f32x2_t code;
+//   * the build scans the ISA of every kernel and fails on any packed fp32 instruction with an op_sel bit set (build.py scan_isa);
+//   * code that multiplies crosswise (rotate_half) uses the single-instruction helpers below.
+__device__ __forceinline__ float v_mul1(float a, float b) {
+  float r;
+  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float v_fma1(float a, float b, float c) {
+  float r;
+  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// a value the compiler must keep in a VGPR of its own (not the high half of a 64-bit pair): {x, x} splats of it use op_sel_hi only
+__device__ __forceinline__ float own_vgpr(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+// RoPE on the rotate_half partners (n1, n2) = dims (d, d + 64): x*cos + rotate_half(x)*sin, rotate_half = cat(-x2, x1)
+// (src/layers.rs:361-375) -- six single VALU instructions
+__device__ __forceinline__ void rope_rotate(float n1, float n2, float c, float sn, float& x1, float& x2) {
+  const float a = v_mul1(sn, n2), b = v_mul1(sn, n1);
+  x1 = v_fma1(c, n1, -a);
+  x2 = v_mul1(c, n2) + b;
+}
+
 // One wave per 128-wide head vector; the lane owns dims (lane, lane+64) = the rotate_half partners.
-// per-head RMSNorm (src/layers.rs:303-304,48-54) then RoPE x*cos + rotate_half(x)*sin (layers.rs:361-375)
+// per-head RMSNorm (src/layers.rs:303-304,48-54) then RoPE (layers.rs:361-375)
+// VAR: 1 = product.  -DQ3A_ROPE_EXPERIMENT builds (never the product library; knob `rope_variant`) add the forms that isolated the
+// hazard: 0 = plain C++ as hipcc SLP-packs it (v_pk_mul_f32 with crossed op_sel), 2 = 0 with idle cycles between the norm multiply
+// and the rotation, 3 = hand-written v_pk_mul_f32, operands swapped in registers, no op_sel, 4 = the swap done by op_sel:[0,1]
+// op_sel_hi:[0,0], 5 = 4 with a destination that overlaps no source.  Measured (32-clip prefills next to a second busy engine,
+// wrong vectors among 250 x 28 x 21504): 0: 232, 1: 0, 2: (31 events), 3: 0, 4: 211, 5: 309.
+template <int VAR = 1>
 __device__ __forceinline__ void head_norm_rope(float& x1, float& x2, const float* __restrict__ w, float eps,
                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                int pos, int lane) {
   const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
   const float rstd = 1.0f / sqrtf(ss / 128.0f + eps);
-  const float n1 = (x1 * rstd) * w[lane], n2 = (x2 * rstd) * w[lane + 64];
   const float c = cos_t[(size_t)pos * 64 + lane], sn = sin_t[(size_t)pos * 64 + lane];
-  x1 = n1 * c + (-n2) * sn;  // rotate_half = cat(-x2, x1)
-  x2 = n2 * c + n1 * sn;
+#ifdef Q3A_ROPE_EXPERIMENT
+  if constexpr (VAR == 3 || VAR == 4 || VAR == 5) {
+    const float n1 = v_mul1(v_mul1(x1, rstd), w[lane]), n2 = v_mul1(v_mul1(x2, rstd), w[lane + 64]);
+    const f32x2_t N = {n1, n2}, C2 = {c, c}, S2 = {sn, sn};
+    f32x2_t A, Bv;
+    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(A) : "v"(N), "v"(C2));  // {n1 c, n2 c}
+    if constexpr (VAR == 3) {
+      float m1 = n1, m2 = n2;
+      asm volatile("" : "+v"(m1), "+v"(m2));
+      const f32x2_t Ns = {m2, m1};
+      asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(Bv) : "v"(Ns), "v"(S2));  // {n2 sn, n1 sn}
+    } else if constexpr (VAR == 4) {
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0]" : "=v"(Bv) : "v"(S2), "v"(N));  // {sn n2, sn n1}
+    } else {
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0]" : "=&v"(Bv) : "v"(S2), "v"(N));
+    }
+    x1 = A.x - Bv.x;
+    x2 = A.y + Bv.y;
+    return;
+  } else if constexpr (VAR == 0 || VAR == 2) {
+    float n1 = (x1 * rstd) * w[lane], n2 = (x2 * rstd) * w[lane + 64];
+    if constexpr (VAR == 2) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(n1), "+v"(n2));
+    x1 = n1 * c + (-n2) * sn;
+    x2 = n2 * c + n1 * sn;
+    return;
+  }
+#endif
+  const float n1 = v_mul1(v_mul1(x1, rstd), w[lane]), n2 = v_mul1(v_mul1(x2, rstd), w[lane + 64]);
+  rope_rotate(n1, n2, c, sn, x1, x2);
 }
 
 // KV-cache element types: bf16 (default) or f32 (precise mode)

@@ -111,6 +111,8 @@ Knobs& knobs() {
     env("Q3A_EOS_RUN_AHEAD", k.eos_run_ahead);
     env("Q3A_LIVE_KEY_SPLITS", k.live_key_splits);
     env("Q3A_GEMM16_RING", k.gemm16_ring);
+    env("Q3A_ROPE_VARIANT", k.rope_variant);
+    env("Q3A_DEBUG_ROPE_TWICE", k.rope_twice);
   });
   return k;
 }
@@ -152,6 +154,8 @@ struct q3a_engine {
   DevBuf attn_pm, attn_pl, attn_po;
   DevBuf nn_x, nn_ss;  // pre-normalised residual row for the next skinny GEMM: [32 * hidden] bf16 fragment order, [hidden/16][32] f32
   DevBuf dbg_scratch;  // (debug) RopeKvArgs::dbg_scratch_copy
+  DevBuf dbg_k2, dbg_v2, dbg_q2, dbg_f1, dbg_f2, dbg_rope_log;  // (debug, knob rope_twice) shadow outputs of the re-executed rope kernel; [64 B counters | 64 x 3584 B records]
+  static constexpr int kRopeLogMax = 64;
   DevBuf rope_cur;  // [B][128] cos|sin row of each sequence's current position (kept by argmax_finalize for decode attention)
   DevBuf enc_ctx16, dec_ctx16;  // opts.valu_attention in the default mode: bf16 copy of the fp32 attention context
   DevBuf dec_q16;
@@ -199,8 +203,10 @@ struct q3a_engine {
   const float* wf(uint64_t off) const { return w<float>(off); }
   const uint16_t* wh(uint64_t off) const { return w<uint16_t>(off); }
 
+  // opts.debug_taps: 1 = every tap; 2 = only the small ones a soak run compares (last hidden rows, head input)
+  static bool light_tap(const char* name) { return strcmp(name, "dec_last_hidden") == 0 || strcmp(name, "head_in") == 0; }
   void tap(const char* name, const void* ptr, size_t bytes) {
-    if (!opts.debug_taps || bytes == 0) return;
+    if (!opts.debug_taps || bytes == 0 || (opts.debug_taps == 2 && !light_tap(name))) return;
     DevBuf& t = taps[name];
     t.ensure(bytes);
     tap_bytes[name] = bytes;
@@ -208,7 +214,7 @@ struct q3a_engine {
   }
   // tap of an activation buffer that is bf16 in the default mode and fp32 in the precise mode: always read back as fp32
   void tap_act(const char* name, const void* ptr, size_t elems) {
-    if (!opts.debug_taps || elems == 0) return;
+    if (!opts.debug_taps || elems == 0 || opts.debug_taps == 2) return;
     if (precise()) return tap(name, ptr, elems * 4);
     DevBuf& t = taps[name];
     t.ensure(elems * 4);
@@ -488,6 +494,12 @@ struct q3a_engine {
         act_gemm(enc_ffn, Fn, wh(e.fc2_w), total_T, D, Fn, ep, false);
       }
       if (li == 0) tap("enc_layer0", enc_x.p, Tt * D * 4);
+      static const bool enc_layer_taps = [] { const char* e = getenv("Q3A_DEBUG_LAYER_TAPS"); return e && atoi(e) != 0; }();
+      if (enc_layer_taps && opts.debug_taps == 1) {  // (tools/bisect_layers.py)
+        char name[32];
+        snprintf(name, sizeof(name), "E%02d_x", li);
+        tap(name, enc_x.p, Tt * D * 4);
+      }
     }
     tap("enc_last", enc_x.p, Tt * D * 4);
     KCHK(launch_layernorm(enc_x.as<float>(), wf(L.ln_post_w), wf(L.ln_post_b), enc_ln.as<float>(), total_T, D, 1e-5f, stream, act16(enc_ln)));
@@ -587,10 +599,21 @@ struct q3a_engine {
     HIPCHK(hipMemsetAsync(step_count.p, 0, (size_t)b * 4, stream));
     HIPCHK(hipMemsetAsync(done.p, 0, (size_t)b, stream));
     HIPCHK(hipMemsetAsync(n_done.p, 0, 64, stream));
-    __atomic_store_n(&host_prog[0], 0, __ATOMIC_RELAXED);  // (the stream is idle here: nothing on the device writes these)
-    __atomic_store_n(&host_prog[1], 0, __ATOMIC_RELAXED);
     HIPCHK(hipMemsetAsync(out_ids.p, 0, (size_t)b * max_new * 4, stream));
+    // drain the stream -- and the group streams: a run that threw mid-loop may have left run-ahead steps enqueued whose
+    // argmax_finalize would still write the progress words -- BEFORE the words are reset
     HIPCHK(hipStreamSynchronize(stream));
+    for (auto cs : chain_streams) HIPCHK(hipStreamSynchronize(cs));
+    __atomic_store_n(&host_prog[0], 0, __ATOMIC_RELAXED);
+    __atomic_store_n(&host_prog[1], 0, __ATOMIC_RELAXED);
+    drain_retired_graphs();
+    {  // a step-visible buffer was reallocated: cached graphs may replay launches that point at the freed allocation
+      DevBuf* step_bufs[] = {&kcache, &vcache, &x_dec, &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits,
+                             &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po, &nn_x, &nn_ss, &rope_cur, &rope_cos, &rope_sin, &xcd_sync, &n_done, &forced_tok};
+      bool any = false;
+      for (auto* sb : step_bufs) { any = any || sb->grew; sb->grew = false; }
+      if (any) drop_graphs();
+    }
   }
 
   void* kc_layer(int l) { return (uint8_t*)kcache.p + (size_t)l * kv_layer_elems * kv_elem(); }
@@ -672,7 +695,21 @@ struct q3a_engine {
       rk.q16 = valu_attn ? nullptr : dec_q16.as<uint16_t>();
       if (fuse_rope) {
         // batch-sized prefill: QK-norm, RoPE and the cache append are the epilogue of the qkv GEMM (k_gemm256.hip)
+        const int M1 = gemm256_split_rows(total_P, QKV);
+        const bool twice = knobs().rope_twice.load() != 0 && M1 > 0;
+        if (twice) { dbg_f1.ensure((size_t)(total_P - M1) * QKV * 4); dbg_f2.ensure((size_t)(total_P - M1) * QKV * 4); rk.dbg_f32 = dbg_f1.as<float>(); }
         KCHK(launch_gemm256_qkrope(dec_ln.as<uint16_t>(), H, wh(l.qkv_w), total_P, H, qkv_bias ? wf(l.qkv_b) : nullptr, rk, stream));
+        if (twice) {
+          // (debug) the trailing rows' fp32 scratch is still intact: run the rope kernel on it again into shadow buffers and compare
+          dbg_k2.ensure(kv_layer_elems * 2); dbg_v2.ensure(kv_layer_elems * 2); dbg_q2.ensure((size_t)total_P * QD * 2);
+          if (!dbg_rope_log.p) { dbg_rope_log.ensure(64 + (size_t)kRopeLogMax * 3584); HIPCHK(hipMemsetAsync(dbg_rope_log.p, 0, dbg_rope_log.cap, stream)); }
+          RopeKvArgs r1 = rk;
+          r1.row_seq += M1; r1.row_pos += M1; r1.q16 += (size_t)M1 * d.n_q * 128;
+          RopeKvArgs r2 = r1;
+          r2.kcache = dbg_k2.p; r2.vcache = dbg_v2.p; r2.q16 = dbg_q2.as<uint16_t>() + (size_t)M1 * d.n_q * 128; r2.dbg_f32 = dbg_f2.as<float>();
+          KCHK(launch_qknorm_rope_kv(r2, total_P - M1, false, stream));
+          KCHK(launch_rope_compare(r1, r2, total_P - M1, li, dbg_rope_log.as<unsigned>(), (uint8_t*)dbg_rope_log.p + 64, kRopeLogMax, stream));
+        }
       } else {
         GemmEpilogue ep; ep.out = dec_qkv.as<float>(); ep.ldo = QKV; ep.bias = qkv_bias ? wf(l.qkv_b) : nullptr;
         act_gemm(dec_ln, H, wh(l.qkv_w), total_P, QKV, H, ep, false);
@@ -931,8 +968,11 @@ struct q3a_engine {
   }
   hipGraphExec_t graph_for_step() {
     const std::string sig = make_graph_sig();
-    for (auto& e : graph_cache)
-      if (e.first == sig) return e.second;
+    for (size_t i = 0; i < graph_cache.size(); ++i)
+      if (graph_cache[i].first == sig) {  // LRU: a hit moves the entry to the back, eviction takes the front
+        if (i + 1 != graph_cache.size()) std::rotate(graph_cache.begin() + i, graph_cache.begin() + i + 1, graph_cache.end());
+        return graph_cache.back().second;
+      }
     hipGraph_t g = nullptr;
     hipGraphExec_t exec = nullptr;
     HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -949,11 +989,26 @@ struct q3a_engine {
     (void)hipGraphDestroy(g);
     HIPCHK(ie);
     if (graph_cache.size() >= kGraphCacheMax) {
-      (void)hipGraphExecDestroy(graph_cache.front().second);
+      // the natural-EOS loop does not synchronise between steps, so the evicted exec may still be executing: it is only
+      // destroyed after the next stream synchronisation (drain_retired_graphs)
+      retired_graphs.push_back(graph_cache.front().second);
       graph_cache.erase(graph_cache.begin());
     }
     graph_cache.emplace_back(sig, exec);
     return exec;
+  }
+  std::vector<hipGraphExec_t> retired_graphs;
+  // call only when the stream is known to be idle
+  void drain_retired_graphs() {
+    for (auto ge : retired_graphs) (void)hipGraphExecDestroy(ge);
+    retired_graphs.clear();
+  }
+  // every cached graph holds raw device addresses: none may outlive a reallocation of ANY step-visible buffer (the signature
+  // names only some of them).  Call with the stream idle.
+  void drop_graphs() {
+    drain_retired_graphs();
+    for (auto& ge : graph_cache) (void)hipGraphExecDestroy(ge.second);
+    graph_cache.clear();
   }
 
   void decode_steps(int n) {
@@ -1074,7 +1129,7 @@ struct q3a_engine {
   bool head_logits_ = true;  // store the logits of a batched decode step (step API, debug taps); off inside run_resident
 
   ~q3a_engine() {
-    for (auto& ge : graph_cache) (void)hipGraphExecDestroy(ge.second);
+    drop_graphs();
     for (auto cs : chain_streams) (void)hipStreamDestroy(cs);
     for (auto ce : join_ev) (void)hipEventDestroy(ce);
     if (fork_ev) (void)hipEventDestroy(fork_ev);
@@ -1083,7 +1138,7 @@ struct q3a_engine {
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
                       &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
                       &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po,
-                      &enc_ctx16, &dec_ctx16, &dec_q16, &xcd_sync, &zero_page, &rope_cur, &nn_x, &nn_ss, &n_done};
+                      &enc_ctx16, &dec_ctx16, &dec_q16, &xcd_sync, &zero_page, &rope_cur, &nn_x, &nn_ss, &n_done, &dbg_scratch, &dbg_k2, &dbg_v2, &dbg_q2, &dbg_f1, &dbg_f2, &dbg_rope_log};
     for (auto* b : bufs) b->release();
     for (auto& kv : taps) kv.second.release();
     if (own_arena && arena) (void)hipFree(arena);
@@ -1463,6 +1518,16 @@ int32_t q3a_debug_read(q3a_engine* e, const char* name, void* dst, uint64_t byte
   if (!e) return 1;
   Q3A_TRY(e)
   HIPCHK(hipSetDevice(e->device));
+  if (strcmp(name, "rope_twice_log") == 0) {  // (debug, knob rope_twice) counters + mismatch records of launch_rope_compare
+    const size_t n = e->dbg_rope_log.cap;
+    if (actual) *actual = n;
+    if (dst && n) {
+      if (bytes < n) fail("q3a_debug_read: destination too small");
+      HIPCHK(hipStreamSynchronize(e->stream));
+      HIPCHK(hipMemcpy(dst, e->dbg_rope_log.p, n, hipMemcpyDeviceToHost));
+    }
+    return 0;
+  }
   auto it = e->taps.find(name);
   if (it == e->taps.end()) fail(std::string("q3a_debug_read: no tap named '") + name + "' (opts.debug_taps set?)");
   size_t n = e->tap_bytes[name];
@@ -1488,6 +1553,8 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (strcmp(key, "eos_run_ahead") == 0) { kn.eos_run_ahead = value; return 0; }
   if (strcmp(key, "live_key_splits") == 0) { kn.live_key_splits = value; return 0; }
   if (strcmp(key, "gemm16_ring") == 0) { kn.gemm16_ring = value; return 0; }
+  if (strcmp(key, "rope_variant") == 0) { kn.rope_variant = value; return 0; }
+  if (strcmp(key, "rope_twice") == 0) { kn.rope_twice = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";
   return 1;
 }

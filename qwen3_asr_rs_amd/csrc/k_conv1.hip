@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void conv1_pair_kernel(const float* __restrict
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
-            const float x = in_l[2 * r + kh][ow * 2 + kw];
+            const float x = own_vgpr(in_l[2 * r + kh][ow * 2 + kw]);  // (not the high half of a ds_read2 pair: dev.h, op_sel hazard)
             acc += wv[kh * 3 + kw] * f32x2_t{x, x};
           }
         const f32x2_t g = gelu_fast2(acc);

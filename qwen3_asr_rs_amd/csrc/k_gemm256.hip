@@ -577,6 +577,8 @@ static int split_rows(int M, int N) {
   return (rows_m >= 1 && M1 < M) ? M1 : 0;
 }
 
+int gemm256_split_rows(int M, int N) { return split_rows(M, N); }
+
 const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
                            bool glu, hipStream_t s) {
   if (M <= 0) return nullptr;

@@ -64,7 +64,9 @@ struct Knobs {
   std::atomic<int> skinny_q{1};                 // Q3A_SKINNY_Q: quarter workgroups for the o / down projections
   std::atomic<int> fuse_qkv_attn{0};            // Q3A_FUSE_QKV_ATTN: one-sequence decode qkv projection + attention in one launch
   std::atomic<int> eos_run_ahead{2};            // Q3A_EOS_RUN_AHEAD: decode steps kept enqueued ahead of the device in natural-EOS mode
-  std::atomic<int> gemm16_ring{0};              // Q3A_GEMM16_RING: 3-4-stage LDS rings with counted vmcnt in the small-M GEMMs (default: two stages)
+  std::atomic<int> gemm16_ring{1};              // Q3A_GEMM16_RING: 3-4-stage LDS rings with counted vmcnt in the small-M GEMMs (0: two stages, one barrier per K tile)
+  std::atomic<int> rope_variant{0};             // Q3A_ROPE_VARIANT (experiment): arithmetic form of qknorm_rope_kv_kernel (dev.h head_norm_rope)
+  std::atomic<int> rope_twice{0};               // Q3A_DEBUG_ROPE_TWICE (debug): re-execute the trailing rows' rope kernel into shadow buffers and compare
   std::atomic<int> live_key_splits{1};          // Q3A_LIVE_KEY_SPLITS: one-sequence decode attention launches the key splits the caches HOLD keys for (0: as many as they have room for)
 };
 Knobs& knobs();
@@ -146,10 +148,18 @@ struct RopeKvArgs {
   int n_q, n_kv, max_ctx;
   uint16_t* q16;            // non-null (default mode, MFMA attention): q is written HERE as bf16 [rows][n_q*128] -- the value the
                             // attention kernel rounds it to on load anyway -- instead of in place as fp32 (half the bytes twice)
+  float* dbg_f32 = nullptr;          // debug (knob rope_twice): fp32 copy of what this launch produced, [rows][n_q + 2 n_kv][128]
   void* dbg_scratch_copy = nullptr;  // debug (Q3A_DEBUG_LAYER_TAPS + Q3A_DEBUG_SCRATCH_COPY): launch_gemm256_qkrope copies the trailing rows'
                                      // fp32 scratch here BETWEEN the small GEMM and the rope kernel
 };
 const char* launch_qknorm_rope_kv(const RopeKvArgs& a, int rows, bool kv_f32, hipStream_t s);
+// (debug) compare the q / K / V rows two executions of the kernel above wrote (b: shadow buffers); counters[1] += mismatching
+// vectors, each of the first max_log of which leaves a 3584-byte record in log (k_decode.hip)
+const char* launch_rope_compare(const RopeKvArgs& a, const RopeKvArgs& b, int rows, int layer, unsigned* counters, void* log,
+                                int max_log, hipStream_t s);
+// rows [0, M1) of an M x N problem that launch_gemm256 / launch_gemm256_qkrope give to the 256 x 256 kernel when they split off
+// the trailing rows (0: no split)
+int gemm256_split_rows(int M, int N);
 // qkv projection (bf16 X [M][K] . W[(n_q + 2 n_kv) * 128][K]^T + bias) with the kernel above as its epilogue: q -> a.q16, k / v
 // -> bf16 KV cache; a.qkv is not touched.  256 x 256 tiles (k_gemm256.hip): call when gemm256_eligible(M, N, K).
 const char* launch_gemm256_qkrope(const uint16_t* X, int lda, const uint16_t* W, int M, int K, const float* bias,

@@ -203,6 +203,15 @@ class HipEngine:
         self._chk(self._lib.q3a_debug_read(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
         return out
 
+    def debug_read_raw(self, name: str) -> np.ndarray:
+        """The same as bytes (records of mixed types: tools/soak_engines.py)."""
+        n = C.c_uint64()
+        self._chk(self._lib.q3a_debug_read(self._h, name.encode(), None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        if n.value:
+            self._chk(self._lib.q3a_debug_read(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out
+
 
 class HipGroup:
     """q3a_group: one process, one host thread per GPU; weights loaded once and replicated with one RCCL broadcast;

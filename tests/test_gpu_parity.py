@@ -50,8 +50,8 @@ def test_gemm_against_device_reference(shape, split):
 ])
 def test_gemm16_against_device_reference(shape):
     """bf16-activation LDS-DMA GEMM (default mode) vs the fp64-accumulating device reference on the same bf16 inputs:
-    products are exact, only the fp32 summation order differs.  Both stagings: two LDS buffers (default) and the
-    3-4-stage rings with counted vmcnt (knob gemm16_ring)."""
+    products are exact, only the fp32 summation order differs.  Both stagings: the 3-4-stage rings with counted vmcnt
+    (default) and two LDS buffers (knob gemm16_ring = 0)."""
     from qwen3_asr_rs_amd import _lib
     from qwen3_asr_rs_amd.engine import selftest_gemm16
     lib = _lib.load()
@@ -61,7 +61,7 @@ def test_gemm16_against_device_reference(shape):
             r = selftest_gemm16(*shape)
             assert r["err"] <= 2e-5 * max(r["ref_max"], 1.0), (ring, r)
     finally:
-        lib.q3a_debug_set(b"gemm16_ring", 0)
+        lib.q3a_debug_set(b"gemm16_ring", 1)
 
 
 def test_mel_reference_clips_and_hf_golden(tiny_dir):
@@ -403,15 +403,12 @@ def test_two_engines_on_one_gpu_share_an_arena_from_two_host_threads(tiny_dir):
     for t in th: t.start()
     for t in th: t.join()
     assert not errs, errs
-    # Thread safety is what this test is for: no error, every batch complete.  Token-for-token equality with the engine
-    # that ran alone holds in (nearly) every run; DESIGN.md section 8 documents a rare run-to-run difference of the
-    # prefill while SEVERAL engines are busy on one GPU (about one 32-clip prefill in 300, open), so a single differing
-    # utterance does not fail the round -- more than one does.
-    differing = 0
+    # every batch complete and token-for-token equal to the engine that ran alone (round 3 tolerated one differing utterance
+    # here: the packed-fp32 op_sel hazard of csrc/dev.h, gone since the round-4 build; tests/test_gpu_soak.py is the long version)
     for i in range(2):
         assert len(got[i]) == 6 and all(len(g) == len(ref[i]) and all(len(u) == 24 for u in g) for g in got[i]), i
-        differing += sum(u != r for g in got[i] for u, r in zip(g, ref[i]))
-    assert differing <= 1, differing
+        differing = sum(u != r for g in got[i] for u, r in zip(g, ref[i]))
+        assert differing == 0, (i, differing)
     # the same two engines one after the other (nothing else on the GPU): exact
     for i in range(2):
         assert engs[i].transcribe_batch(work[i], None, max_new=24, fixed_new_tokens=24) == ref[i]

@@ -15,11 +15,12 @@ clips = [synthetic.synthetic_clip(i, 30.0) for i in range(B)]
 arena = pack_arena_host(d).to("cuda:0"); torch.cuda.synchronize()
 A = HipEngine(d, 0, max_new_tokens=16, debug_taps=True, device_arena=(arena.data_ptr(), arena.numel()))
 Bg = HipEngine(d, 0, max_new_tokens=100, device_arena=(arena.data_ptr(), arena.numel()))
+ENC_ORDER = ["conv3", "enc_in"] + [f"E{li:02d}_x" for li in range(18)] + ["enc_last", "audio_embeds", "dec_embed"]
 ORDER = [f"L{li:02d}_{w}" for li in range(28) for w in (("qkvm",) if os.environ.get("Q3A_DEBUG_SCRATCH_COPY") else ()) + ("qkvs", "k", "v", "attn", "o", "ln2", "act", "x")]
 def run(): return A.transcribe_batch(clips, None, max_new=2, fixed_new_tokens=2)
 run()
 ref_last = A.debug_read("dec_last_hidden").copy()
-ref = {k: A.debug_read(k).view(np.uint8).copy() for k in ORDER}
+ref = {k: A.debug_read(k).view(np.uint8).copy() for k in ENC_ORDER + ORDER}
 print("reference snapshot:", sum(v.nbytes for v in ref.values()) >> 20, "MiB", flush=True)
 stop = False
 def load():
@@ -31,6 +32,20 @@ for it in range(RUNS):
     if (A.debug_read("dec_last_hidden").view(np.uint32) == ref_last.view(np.uint32)).all(): continue
     events += 1
     print(f"run {it}: last hidden rows differ", flush=True)
+    enc_hit = False
+    for k in ENC_ORDER:  # encoder-side taps first (fp32 / fp32 copies of bf16 maps): which stage, which rows
+        cur = A.debug_read(k).view(np.uint8)
+        ne = cur != ref[k]
+        if ne.any():
+            el = np.unique(np.nonzero(ne)[0] // 4)
+            cols = {"mel": 1, "conv1": 480, "conv2": 480, "conv3": 480, "audio_embeds": 1024, "dec_embed": 1024}.get(k, 896)
+            rows = np.unique(el // cols)
+            print(f"   first differing ENCODER-side buffer {k}: {len(el)} elements; rows (of {cols} columns) {rows.min()}..{rows.max()} ({len(rows)} distinct): {rows[:16]}; cols {np.unique(el % cols)[:24]}", flush=True)
+            a_, b_ = cur.view(np.float32)[el[:8]], ref[k].view(np.float32)[el[:8]]
+            print(f"      now {a_}\n      ref {b_}", flush=True)
+            enc_hit = True
+            break
+    if enc_hit: continue
     for k in ORDER:
         cur = A.debug_read(k).view(np.uint8)
         ne = cur != ref[k]

@@ -1,0 +1,122 @@
+"""Soak of several engines busy on ONE GPU: engine A repeats one batch (encoder + prefill + 2 tokens) and its
+last hidden rows / ids are compared bit for bit with its own first run, while `--load` further engines keep the GPU busy from their
+own host threads.  Knobs come from the environment (Q3A_GEMM16_RING, Q3A_ROPE_VARIANT, Q3A_DEBUG_ROPE_TWICE, Q3A_GEMM256_SPLIT_REM, ...).
+With Q3A_DEBUG_ROPE_TWICE=1 the trailing rows' rope kernel is executed twice per layer and every mismatch between the two executions
+is dumped and analysed (which execution is wrong, which lanes, which operand the wrong value is consistent with).
+
+    python tools/soak_engines.py --runs 300 --load 1 [--batch 32] [--tokens 2] [--stop-after 0]
+Prints one summary line that starts with SOAK."""
+import argparse, os, sys, time, threading
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from qwen3_asr_rs_amd import synthetic
+from qwen3_asr_rs_amd.engine import HipEngine
+from qwen3_asr_rs_amd.distributed import pack_arena_host
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--runs", type=int, default=300)
+ap.add_argument("--load", type=int, default=1)
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--tokens", type=int, default=2)
+ap.add_argument("--load-tokens", type=int, default=100)
+ap.add_argument("--stop-after", type=int, default=0, help="stop after this many events (0: never)")
+ap.add_argument("--seconds", type=float, default=0.0, help="time budget (0: none)")
+ap.add_argument("--tag", default="")
+args = ap.parse_args()
+
+B = args.batch
+d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b_pipe", "0.6b", seed=0)
+clips = [synthetic.synthetic_clip(i, 30.0) for i in range(B)]
+arena = pack_arena_host(d).to("cuda:0"); torch.cuda.synchronize()
+arena_arg = (arena.data_ptr(), arena.numel())
+A = HipEngine(d, 0, max_new_tokens=16, debug_taps=2, device_arena=arena_arg)
+loads = [HipEngine(d, 0, max_new_tokens=args.load_tokens, device_arena=arena_arg) for _ in range(args.load)]
+twice = os.environ.get("Q3A_DEBUG_ROPE_TWICE", "0") not in ("", "0")
+
+
+def run():
+    return A.transcribe_batch(clips, None, max_new=args.tokens, fixed_new_tokens=args.tokens)
+
+
+ref_ids = run()
+ref_last = A.debug_read("dec_last_hidden").view(np.uint32).copy()
+solo_bad = 0
+for _ in range(3):  # alone on the GPU the result must repeat bit for bit
+    ids = run()
+    solo_bad += int(ids != ref_ids or not (A.debug_read("dec_last_hidden").view(np.uint32) == ref_last).all())
+stop = False
+
+
+def load(e):
+    while not stop:
+        e.transcribe_batch(clips, None, max_new=args.load_tokens, fixed_new_tokens=args.load_tokens)
+
+
+threads = [threading.Thread(target=load, args=(e,)) for e in loads]
+for t in threads: t.start()
+time.sleep(0.3)
+events, id_events, done, t0 = 0, 0, 0, time.perf_counter()
+for it in range(args.runs):
+    ids = run()
+    done += 1
+    cur = A.debug_read("dec_last_hidden").view(np.uint32)
+    if not (cur == ref_last).all():
+        events += 1
+        rows = np.nonzero((cur.reshape(B, -1) != ref_last.reshape(B, -1)).any(axis=1))[0]
+        idd = [u for u in range(B) if ids[u] != ref_ids[u]]
+        id_events += int(bool(idd))
+        print(f"  run {it}: last hidden rows of utterances {rows.tolist()} differ; ids differ for {idd}", flush=True)
+        if args.stop_after and events >= args.stop_after: break
+    if args.seconds and time.perf_counter() - t0 > args.seconds: break
+dt = time.perf_counter() - t0
+stop = True
+for t in threads: t.join()
+
+mism = 0
+if twice:
+    raw = A.debug_read_raw("rope_twice_log")
+    mism = int(raw[:64].view(np.uint32)[1]) if raw.size else 0
+    eps = 1e-6
+    bf = lambda u16: (u16.astype(np.uint32) << 16).view(np.float32)
+    for i in range(min(mism, 64)):
+        e = raw[64 + i * 3584: 64 + (i + 1) * 3584]
+        hdr = e[:32].view(np.int32)
+        ra, rb = bf(e[32:288].view(np.uint16)), bf(e[288:544].view(np.uint16))
+        f = e[544:544 + 640 * 4].view(np.float32)
+        x, w, c, sn, fa, fb = f[0:128], f[128:256], f[256:320], f[320:384], f[384:512], f[512:640]
+        x1, x2 = x[:64].astype(np.float32), x[64:].astype(np.float32)
+        rstd = np.float32(1.0) / np.sqrt(np.float32((x.astype(np.float64) ** 2).sum() / 128.0 + eps), dtype=np.float32)
+        has_w = bool(hdr[5])
+        if has_w:
+            n1, n2 = (x1 * rstd) * w[:64], (x2 * rstd) * w[64:]
+            e1, e2 = n1 * c - n2 * sn, n2 * c + n1 * sn
+        else:
+            n1, n2, e1, e2 = x1, x2, x1, x2
+        exp = np.concatenate([e1, e2]).astype(np.float32)
+        da, db = np.abs(fa - exp), np.abs(fb - exp)
+        tol = 1e-5 * np.maximum(1.0, np.abs(exp))
+        bad_a, bad_b = np.nonzero(da > tol)[0], np.nonzero(db > tol)[0]
+        kind = "q" if hdr[2] < 16 else ("k" if hdr[2] < 24 else "v")
+        print(f"  mismatch {i}: layer {hdr[0]} row {hdr[1]} vec {hdr[2]} ({kind}) pos {hdr[3]} seq {hdr[4]}: bf16 lanes differing "
+              f"{np.nonzero(ra != rb)[0].tolist()}; fp32 off-expectation elements: first execution {bad_a.tolist()}, second {bad_b.tolist()}", flush=True)
+        for name, fw, bad in (("first", fa, bad_a), ("second", fb, bad_b)):
+            for j in bad[:6]:
+                l = j % 64
+                if has_w and j >= 64:   # x2' = n2 c + n1' sn  ->  the n1 the wrong result implies
+                    imp = (np.float64(fw[j]) - np.float64(np.float32(n2[l] * c[l]))) / np.float64(sn[l])
+                    cand = {"n1": n1[l], "x1*rstd": x1[l] * rstd, "x1": x1[l], "w1": w[l], "n2": n2[l], "x2*rstd": x2[l] * rstd, "0": 0.0,
+                            "n1[l-16]": n1[l - 16], "n1[l^32]": n1[l ^ 32], "sn": sn[l], "c": c[l]}
+                elif has_w:             # x1' = n1 c - n2' sn
+                    imp = (np.float64(np.float32(n1[l] * c[l])) - np.float64(fw[j])) / np.float64(sn[l])
+                    cand = {"n2": n2[l], "x2*rstd": x2[l] * rstd, "x2": x2[l], "w2": w[64 + l], "n1": n1[l], "0": 0.0}
+                else:
+                    imp, cand = float(fw[j]), {"x": exp[j]}
+                best = min(cand, key=lambda k: abs(cand[k] - imp))
+                print(f"      {name} execution elem {j} (lane {l}): got {fw[j]:.7f} expected {exp[j]:.7f}; implied operand {imp:.6f}; "
+                      f"closest candidate {best} = {cand[best]:.6f}; all: " + ", ".join(f"{k}={v:.5f}" for k, v in cand.items()), flush=True)
+print(f"SOAK{(' ' + args.tag) if args.tag else ''}: {events} event(s) ({id_events} with differing ids) in {done} runs of {B} clips, {args.load} load engine(s), "
+      f"{dt:.1f} s, solo repeats differing {solo_bad}, ring={os.environ.get('Q3A_GEMM16_RING', '0')} rope_variant={os.environ.get('Q3A_ROPE_VARIANT', '0')} "
+      f"split_rem={os.environ.get('Q3A_GEMM256_SPLIT_REM', 'default')} lib={os.path.basename(os.environ.get('Q3A_LIB', 'libq3asr_hip.so'))}"
+      + (f" rope_twice mismatching vectors {mism}" if twice else ""), flush=True)
+A.close()
+for e in loads: e.close()
