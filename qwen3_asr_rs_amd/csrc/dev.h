@@ -161,33 +161,26 @@ __device__ __forceinline__ float lane_bcast(float v, int lane_uniform) {
 // no op_sel never fails; tools/soak_engines.py + the Q3A_ROPE_EXPERIMENT variants below).  Consequences for this library:
 //   * it is built with -fno-slp-vectorize (qwen3_asr_rs_amd/build.py), so packed fp32 only comes from explicit f32x2_t code;
 //   * the build scans the ISA of every kernel and fails on any packed fp32 instruction with an op_sel bit set (build.py scan_isa);
-//   * code that multiplies crosswise (rotate_half) uses the single-instruction helpers below.
-__device__ __forceinline__ float v_mul1(float a, float b) {
-  float r;
-  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float v_fma1(float a, float b, float c) {
-  float r;
-  asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+//   * no arithmetic in inline asm as a way around the packing: hipcc's hazard recogniser does not look inside asm blocks (a
+//     v_mul_f32 written in asm straight behind the v_rsq_f32 that produced its operand -- the gfx940+ trans-op forwarding
+//     hazard -- read a stale value now and then: round 4, the decode attention's q/k norm, caught by the graph == eager id test).
 // a value the compiler must keep in a VGPR of its own (not the high half of a 64-bit pair): {x, x} splats of it use op_sel_hi only
+// (an empty asm block: no instruction is emitted)
 __device__ __forceinline__ float own_vgpr(float x) {
   asm volatile("" : "+v"(x));
   return x;
 }
 // RoPE on the rotate_half partners (n1, n2) = dims (d, d + 64): x*cos + rotate_half(x)*sin, rotate_half = cat(-x2, x1)
-// (src/layers.rs:361-375) -- six single VALU instructions
+// (src/layers.rs:361-375): two multiplies + two fused multiply-adds, scalar (see above)
 __device__ __forceinline__ void rope_rotate(float n1, float n2, float c, float sn, float& x1, float& x2) {
-  const float a = v_mul1(sn, n2), b = v_mul1(sn, n1);
-  x1 = v_fma1(c, n1, -a);
-  x2 = v_mul1(c, n2) + b;
+  const float a = sn * n2, b = sn * n1;
+  x1 = __builtin_fmaf(c, n1, -a);
+  x2 = __builtin_fmaf(c, n2, b);
 }
 
 // One wave per 128-wide head vector; the lane owns dims (lane, lane+64) = the rotate_half partners.
 // per-head RMSNorm (src/layers.rs:303-304,48-54) then RoPE (layers.rs:361-375)
-// VAR: 1 = product.  -DQ3A_ROPE_EXPERIMENT builds (never the product library; knob `rope_variant`) add the forms that isolated the
+// VAR: 1 = product (plain scalar C++; with the SLP vectoriser off it stays scalar, and the build's ISA scan checks that).  -DQ3A_ROPE_EXPERIMENT builds (never the product library; knob `rope_variant`) add the forms that isolated the
 // hazard: 0 = plain C++ as hipcc SLP-packs it (v_pk_mul_f32 with crossed op_sel), 2 = 0 with idle cycles between the norm multiply
 // and the rotation, 3 = hand-written v_pk_mul_f32, operands swapped in registers, no op_sel, 4 = the swap done by op_sel:[0,1]
 // op_sel_hi:[0,0], 5 = 4 with a destination that overlaps no source.  Measured (32-clip prefills next to a second busy engine,
@@ -201,7 +194,7 @@ __device__ __forceinline__ void head_norm_rope(float& x1, float& x2, const float
   const float c = cos_t[(size_t)pos * 64 + lane], sn = sin_t[(size_t)pos * 64 + lane];
 #ifdef Q3A_ROPE_EXPERIMENT
   if constexpr (VAR == 3 || VAR == 4 || VAR == 5) {
-    const float n1 = v_mul1(v_mul1(x1, rstd), w[lane]), n2 = v_mul1(v_mul1(x2, rstd), w[lane + 64]);
+    const float n1 = (x1 * rstd) * w[lane], n2 = (x2 * rstd) * w[lane + 64];
     const f32x2_t N = {n1, n2}, C2 = {c, c}, S2 = {sn, sn};
     f32x2_t A, Bv;
     asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(A) : "v"(N), "v"(C2));  // {n1 c, n2 c}
@@ -226,7 +219,7 @@ __device__ __forceinline__ void head_norm_rope(float& x1, float& x2, const float
     return;
   }
 #endif
-  const float n1 = v_mul1(v_mul1(x1, rstd), w[lane]), n2 = v_mul1(v_mul1(x2, rstd), w[lane + 64]);
+  const float n1 = (x1 * rstd) * w[lane], n2 = (x2 * rstd) * w[lane + 64];
   rope_rotate(n1, n2, c, sn, x1, x2);
 }
 

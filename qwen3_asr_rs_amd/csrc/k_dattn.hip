@@ -144,8 +144,8 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
   if (wave <= GROUP) {  // per-head RMSNorm + RoPE (as dev.h head_norm_rope)
     const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
     const float rstd = rstd_of(ss / 128.0f + a.eps, sizeof(KVT) == 2);  // bf16 cache = default mode: hardware rsq
-    const float n1 = v_mul1(v_mul1(x1, rstd), nw1), n2 = v_mul1(v_mul1(x2, rstd), nw2);
-    rope_rotate(n1, n2, c, sn, x1, x2);  // single VALU instructions (dev.h: packed fp32 + op_sel hazard)
+    const float n1 = (x1 * rstd) * nw1, n2 = (x2 * rstd) * nw2;
+    rope_rotate(n1, n2, c, sn, x1, x2);
   }
   if (wave < GROUP) {
     q_s[wave][lane] = x1;
@@ -491,8 +491,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   if (wave <= GROUP) {  // per-head RMSNorm + RoPE (as dev.h head_norm_rope)
     const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
     const float rstd = rstd_of(ss / 128.0f + a.eps, sizeof(KVT) == 2);  // bf16 cache = default mode: hardware rsq
-    const float n1 = v_mul1(v_mul1(x1, rstd), nw1), n2 = v_mul1(v_mul1(x2, rstd), nw2);
-    rope_rotate(n1, n2, c, sn, x1, x2);  // single VALU instructions (dev.h: packed fp32 + op_sel hazard)
+    const float n1 = (x1 * rstd) * nw1, n2 = (x2 * rstd) * nw2;
+    rope_rotate(n1, n2, c, sn, x1, x2);
   }
   if (wave < GROUP) {
     q_s[wave][lane] = x1;
