@@ -13,7 +13,7 @@ the speech rate the survey fixes).  Rank 0 prints ONE JSON line.
 Launching.  N = 1: `python bench.py`.  N > 1: one process per GPU under torch.distributed.run (the driver's command above);
 a bare `python bench.py --gpus N` re-executes itself under torch.distributed.run on 127.0.0.1 with a free port, so the
 same command shape works at every N.  With N > 1 the line also carries an `extra` leg: BASELINE configs[4]'s per-GPU
-workload (Qwen3-ASR-1.7B, 32 clips per GPU, weights shipped with ONE RCCL broadcast of the arena); --native-group-leg adds
+workload (Qwen3-ASR-1.7B, 32 clips per GPU, weights shipped with ONE RCCL broadcast of the arena); the q3a_group_* leg (on by default; --no-native-group-leg) adds
 the native q3a_group_* path (one process, one host thread per GPU, RCCL called from C++).
 
 What is inside the clock
@@ -172,7 +172,7 @@ def make_engine(preset, ckpt_dir, local_rank, precise, new_tokens, arena=None):
     from qwen3_asr_rs_amd import synthetic
     from qwen3_asr_rs_amd.engine import HipEngine
     model_dir = ckpt_dir or f"/tmp/q3a_ckpt_{preset.replace('.', 'p')}"
-    synthetic.write_checkpoint(model_dir, preset, seed=0, shards=2 if preset == "1.7b" else 1)
+    synthetic.write_checkpoint(model_dir, preset, seed=0, shards=2 if preset == "1.7b" else 1, embed_scale=synthetic.PEAKED_EMBED_SCALE)
     kw = {}
     if arena is not None:
         kw["device_arena"] = (arena.data_ptr(), arena.numel())
@@ -237,7 +237,7 @@ def natural_eos_leg(preset, seconds, new_tokens, steps, warmup, precise, fixed_m
     from qwen3_asr_rs_amd import synthetic
     from qwen3_asr_rs_amd.engine import HipEngine
     eos_dir = f"/tmp/q3a_ckpt_{preset.replace('.', 'p')}_eosbench"
-    synthetic.write_checkpoint(eos_dir, preset, seed=0, shards=2 if preset == "1.7b" else 1)
+    synthetic.write_checkpoint(eos_dir, preset, seed=0, shards=2 if preset == "1.7b" else 1, embed_scale=synthetic.PEAKED_EMBED_SCALE)
     key = synthetic.output_embedding_key(eos_dir)
     H = synthetic._locate_tensor(eos_dir, key)[1]["shape"][1]
     synthetic.overwrite_row(eos_dir, key, synthetic.ENDOFTEXT_ID, np.zeros(H, dtype=np.float32))  # un-plant a previous run
@@ -275,7 +275,7 @@ def natural_eos_leg(preset, seconds, new_tokens, steps, warmup, precise, fixed_m
             "vs_fixed_n_ms": round(elapsed / steps * 1e3 - fixed_ms, 3),
             "eos_row_norm": round(info["row_norm"], 2),
             "what": "fixed_new_tokens = 0: stop condition evaluated on the device, polled from pinned host memory, "
-                    "eos_run_ahead = 2 graph replays enqueued ahead (no stream synchronisation inside the loop)"}
+                    "eos_run_ahead = 1 graph replay enqueued ahead (no stream synchronisation inside the loop)"}
 
 
 def free_port() -> int:
@@ -363,7 +363,7 @@ def config4_leg(dist, dev, rank, world, local_rank, seconds, new_tokens, steps, 
     B = 32
     model_dir = "/tmp/q3a_ckpt_1p7b"
     if rank == 0:
-        synthetic.write_checkpoint(model_dir, "1.7b", seed=0, shards=2)
+        synthetic.write_checkpoint(model_dir, "1.7b", seed=0, shards=2, embed_scale=synthetic.PEAKED_EMBED_SCALE)
     dist.barrier()
     t0 = time.perf_counter()
     arena = broadcast_arena(model_dir, dev, src=0)
@@ -406,6 +406,8 @@ def native_group_leg(preset, ckpt_dir, world, B, seconds, new_tokens, steps, pre
     out = {"workload": f"q3a_group_transcribe: Qwen3-ASR-{preset} bf16, {world} GPUs x {B} x {seconds:.0f}s clips, host PCM -> ids",
            "value": round(world * B * seconds * steps / elapsed, 3), "unit": "audio-seconds/sec", "ms_per_step": round(elapsed / steps * 1e3, 3),
            "ranks": grp.size, "used_rccl": grp.used_rccl, "group_create_s": round(t_create, 2),
+           "startup_s": {k: round(v, 3) for k, v in grp.startup_seconds.items()},
+           "stage_ms_per_rank": [{k: round(float(v), 2) for k, v in grp.engine_timings(r).items() if k.endswith("_ms")} for r in range(grp.size)],
            "ids_ok": len(ids) == world * B and all(len(x) == new_tokens for x in ids)}
     grp.close()
     return out
@@ -447,8 +449,8 @@ def main():
     ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child passes (roofline falls back to the microbenchmark)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two PMC child passes (roofline.traffic = null)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs (N = 1: configs[2], configs[3], natural EOS; N > 1: configs[4]'s per-GPU workload)")
-    ap.add_argument("--native-group-leg", action="store_true",
-                    help="N > 1: also time q3a_group_transcribe (one process driving every GPU) on rank 0 while the other ranks wait on a CPU barrier")
+    ap.add_argument("--no-native-group-leg", action="store_true", help="N > 1: skip the q3a_group_* leg (on by default; its error, if any, is captured in the JSON)")
+    ap.add_argument("--native-group-leg", action="store_true", help="(accepted for compatibility: the leg is on by default since round 4)")
     ap.add_argument("--ckpt-dir", default=None)
     ap.add_argument("--trace-out", default=None, help="write the per-kernel table of the in-situ rocprofv3 kernel trace to this file")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)
@@ -488,7 +490,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
         model_dir = args.ckpt_dir or f"/tmp/q3a_ckpt_{args.preset.replace('.', 'p')}"
         if rank == 0:
-            synthetic.write_checkpoint(model_dir, args.preset, seed=0, shards=2 if args.preset == "1.7b" else 1)
+            synthetic.write_checkpoint(model_dir, args.preset, seed=0, shards=2 if args.preset == "1.7b" else 1, embed_scale=synthetic.PEAKED_EMBED_SCALE)
         dist.barrier()
         from qwen3_asr_rs_amd.distributed import broadcast_arena
         arena = broadcast_arena(model_dir, dev, src=0)  # one RCCL broadcast of the weight arena over xGMI
@@ -527,7 +529,7 @@ def main():
             multi_extra.append({"workload": "Qwen3-ASR-1.7b, 32 clips per GPU", "value": None, "error": str(ex)[:300]})
         torch.cuda.synchronize()
         dist.barrier()
-        if args.native_group_leg:
+        if not args.no_native_group_leg:
             # the native one-process group drives every GPU from rank 0's process; the other ranks wait on a gloo (CPU) barrier so
             # that no collective kernel of theirs spins on the GPUs meanwhile
             cpu_pg = dist.new_group(backend="gloo")

@@ -151,6 +151,9 @@ int32_t q3a_group_create(const char* model_dir, int32_t n_gpus, const int32_t* d
 void q3a_group_destroy(q3a_group* g);
 int32_t q3a_group_size(const q3a_group* g);
 int32_t q3a_group_used_rccl(const q3a_group* g);  /* 1 when the arena went through ncclBroadcast */
+/* Start-up stage times of q3a_group_create in seconds: out4 = {pack (read + lay out the checkpoint into pinned host memory),
+ * upload (one asynchronous H2D copy to the first GPU), broadcast (RCCL init + ONE ncclBroadcast of the arena), engines}. */
+int32_t q3a_group_startup_seconds(const q3a_group* g, double* out4);
 const char* q3a_group_last_error(const q3a_group* g);
 q3a_engine* q3a_group_engine(q3a_group* g, int32_t rank);  /* borrowed handle of rank's engine (stage API, timings) */
 /* Static contiguous split of n_items utterances: rank gets [*begin, *end) (the first n_items % world_size ranks one more). */
@@ -245,7 +248,7 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *                        0: 16 rows x 32 sequences (taken at the next engine / batch set-up: it sizes a buffer).
  *   "fuse_qkv_attn"      0 (default) / 1: one-sequence decode runs the qkv projection and the attention key splits as ONE launch
  *                        handed over inside each XCD (8 kv heads x 2 query heads only); taken at the next prefill.
- *   "eos_run_ahead"      decode steps the natural-EOS greedy loop keeps enqueued ahead of the device (default 2): the stop
+ *   "eos_run_ahead"      decode steps the natural-EOS greedy loop keeps enqueued ahead of the device (default 1): the stop
  *                        condition is evaluated on the device and read from pinned host memory without synchronising.
  *   "live_key_splits"    1 (default): the one-sequence decode attention launches as many 128-key splits as the caches HOLD keys
  *                        for (longest prompt + steps so far; the count is part of the graph signature), so max_new_tokens is a

@@ -19,7 +19,7 @@ SYMBOLS = [
     "q3a_load_audio", "q3a_resample", "q3a_resample_rubato", "q3a_free", "q3a_tokenizer_create", "q3a_tokenizer_destroy",
     "q3a_tokenizer_decode", "q3a_tokenizer_encode", "q3a_normalize_nfc", "q3a_parse_asr_output", "q3a_capitalize_first",
     "q3a_group_create", "q3a_group_destroy", "q3a_group_size", "q3a_group_used_rccl", "q3a_group_last_error",
-    "q3a_group_engine", "q3a_group_partition", "q3a_group_transcribe",
+    "q3a_group_engine", "q3a_group_partition", "q3a_group_transcribe", "q3a_group_startup_seconds",
 ]
 
 
@@ -108,6 +108,7 @@ def load() -> C.CDLL:
         "q3a_group_destroy": (None, [P]),
         "q3a_group_size": (i32, [P]),
         "q3a_group_used_rccl": (i32, [P]),
+        "q3a_group_startup_seconds": (i32, [P, C.POINTER(C.c_double)]),
         "q3a_group_last_error": (C.c_char_p, [P]),
         "q3a_group_engine": (P, [P, i32]),
         "q3a_group_partition": (None, [i32, i32, i32, i32p, i32p]),

@@ -17,6 +17,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1051,9 +1052,13 @@ struct q3a_engine {
     HIPCHK(hipEventRecord(ev[3], stream));
     // the prefill already produced token 0; every decode step feeds one token and yields the next
     int steps = 0;
+    static const bool host_timing = [] { const char* e = getenv("Q3A_DEBUG_HOST_TIMING"); return e && atoi(e) != 0; }();
+    const auto h0 = std::chrono::steady_clock::now();
     if (fixed_new > 0) {
       steps = fixed_new - 1;
       decode_steps(steps);
+      if (host_timing) fprintf(stderr, "[q3a host timing] %d graph launches enqueued in %.1f us\n", steps,
+                               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count());
     } else {
       // Natural EOS (inference.rs:160-167).  The stop condition of the whole batch is evaluated on the device
       // (argmax_finalize: n_done == B) and published to pinned host memory together with a progress counter; the host keeps

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -82,6 +83,7 @@ struct q3a_group {
   std::vector<q3a_engine*> engines;
   uint64_t arena_bytes = 0;
   bool used_rccl = false;
+  double startup_s[4] = {0, 0, 0, 0};  // pack (read + lay out the checkpoint), upload (H2D to the first GPU), broadcast, engines
   std::string err;
   ~q3a_group() {
     for (auto* e : engines)
@@ -118,20 +120,35 @@ int32_t q3a_group_create(const char* model_dir, int32_t n_gpus, const int32_t* d
     g->arena_bytes = bytes;
     g->arenas.assign(n_gpus, nullptr);
     g->engines.assign(n_gpus, nullptr);
-    {  // rank 0 reads the checkpoint (weights.rs:10-120) and packs the arena; nobody else touches the files
-      std::vector<uint8_t> host(bytes);
-      if (q3a_arena_pack(model_dir, host.data(), bytes) != 0) fail(q3a_last_error(nullptr));
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    {  // the checkpoint is read ONCE (weights.rs:10-120) and packed straight into pinned host memory: the upload is one
+       // asynchronous DMA at PCIe rate instead of a pageable copy staged through the driver's bounce buffers
+      void* host = nullptr;
+      GHIP(hipSetDevice(g->devices[0]));
+      GHIP(hipHostMalloc(&host, bytes, hipHostMallocDefault));
+      struct Pinned { void* p; ~Pinned() { if (p) (void)hipHostFree(p); } } pinned{host};
+      const auto t0 = now();
+      if (q3a_arena_pack(model_dir, host, bytes) != 0) fail(q3a_last_error(nullptr));
+      const auto t1 = now();
       for (int i = 0; i < n_gpus; ++i) {
         GHIP(hipSetDevice(g->devices[i]));
         GHIP(hipMalloc(&g->arenas[i], bytes));
       }
       GHIP(hipSetDevice(g->devices[0]));
-      GHIP(hipMemcpy(g->arenas[0], host.data(), bytes, hipMemcpyHostToDevice));
+      hipStream_t up = nullptr;
+      GHIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+      GHIP(hipMemcpyAsync(g->arenas[0], host, bytes, hipMemcpyHostToDevice, up));
+      GHIP(hipStreamSynchronize(up));
+      GHIP(hipStreamDestroy(up));
+      g->startup_s[0] = secs(t0, t1);
+      g->startup_s[1] = secs(t1, now());
     }
     const char* force = getenv("Q3A_GROUP_FORCE_RCCL");
     if (n_gpus > 1 || (force && atoi(force) != 0)) {
       // ONE broadcast of the whole arena (1.56 GB at 0.6B, 4.08 GB at 1.7B): xGMI is point-to-point, one large message
       // per link is the cheapest shape; steady state has no collective at all
+      const auto tb = now();
       Rccl r;
       r.load();
       std::vector<ncclComm_t> comms(n_gpus, nullptr);
@@ -154,11 +171,14 @@ int32_t q3a_group_create(const char* model_dir, int32_t n_gpus, const int32_t* d
       }
       for (auto c : comms) r.check(r.CommDestroy(c), "ncclCommDestroy");
       g->used_rccl = true;
+      g->startup_s[2] = secs(tb, now());
     }
+    const auto te = now();
     for (int i = 0; i < n_gpus; ++i) {
       if (q3a_engine_create_from_arena(model_dir, g->devices[i], g->arenas[i], bytes, opts, &g->engines[i]) != 0)
         fail(std::string("q3a_group_create: GPU ") + std::to_string(g->devices[i]) + ": " + q3a_last_error(nullptr));
     }
+    g->startup_s[3] = secs(te, now());
     *out = g.release();
     return 0;
   } catch (const std::exception& ex) {
@@ -171,6 +191,11 @@ int32_t q3a_group_create(const char* model_dir, int32_t n_gpus, const int32_t* d
 void q3a_group_destroy(q3a_group* g) { delete g; }
 int32_t q3a_group_size(const q3a_group* g) { return g ? (int32_t)g->engines.size() : 0; }
 int32_t q3a_group_used_rccl(const q3a_group* g) { return g && g->used_rccl ? 1 : 0; }
+int32_t q3a_group_startup_seconds(const q3a_group* g, double* out4) {
+  if (!g || !out4) return 1;
+  for (int i = 0; i < 4; ++i) out4[i] = g->startup_s[i];
+  return 0;
+}
 const char* q3a_group_last_error(const q3a_group* g) { return g ? g->err.c_str() : q3a_last_error(nullptr); }
 q3a_engine* q3a_group_engine(q3a_group* g, int32_t rank) {
   return (g && rank >= 0 && rank < (int32_t)g->engines.size()) ? g->engines[rank] : nullptr;

@@ -238,6 +238,21 @@ class HipGroup:
     def used_rccl(self) -> bool:
         return bool(self._lib.q3a_group_used_rccl(self._h))
 
+    def engine_timings(self, rank: int) -> dict:
+        """Stage timings of rank's engine for its slice of the last batch (q3a_group_engine + q3a_stage_timings)."""
+        h = self._lib.q3a_group_engine(self._h, rank)
+        t = _lib.Timings()
+        if not h or self._lib.q3a_stage_timings(C.c_void_p(h), C.byref(t)) != 0:
+            return {}
+        return {n: getattr(t, n) for n, _ in _lib.Timings._fields_}
+
+    @property
+    def startup_seconds(self) -> dict:
+        """Stage times of q3a_group_create: checkpoint read + pack, H2D upload to the first GPU, RCCL broadcast, engine creation."""
+        v = (C.c_double * 4)()
+        self._lib.q3a_group_startup_seconds(self._h, v)
+        return {"pack_s": v[0], "upload_s": v[1], "broadcast_s": v[2], "engines_s": v[3]}
+
     def transcribe_batch(self, clips: Sequence[np.ndarray], lang_prefix_ids: Optional[Sequence[int]] = None,
                          max_new: int = 4096, fixed_new_tokens: int = 0) -> List[List[int]]:
         pcm, ns = HipEngine._concat(clips)

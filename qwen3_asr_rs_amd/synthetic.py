@@ -52,6 +52,11 @@ CONFIG_TINY_UNTIED = {
                         num_key_value_heads=2, num_hidden_layers=3,
                         rope_scaling=dict(rope_type="default", mrope_section=[24, 20, 20], mrope_interleaved=False)),
 }
+# Token-embedding std of the checkpoints bench.py times and tests/test_gpu_configs.py checks.  With the 0.02 of the golden
+# fixtures the (tied) logits are nearly flat -- top-1/top-2 gaps of a few hundredths next to a bf16 engine's logit error of
+# ~0.015, so 7-15 % of the greedy steps were undecidable; at 0.04 the gaps are 0.2-0.55 at |logit| <= 6 (measured with the oracle
+# at the 0.6B dimensions), i.e. 10x the rounding noise -- closer to a trained checkpoint's peaked distributions.
+PEAKED_EMBED_SCALE = 0.04
 PRESETS = {"0.6b": CONFIG_0P6B, "1.7b": CONFIG_1P7B, "tiny": CONFIG_TINY, "tiny_untied": CONFIG_TINY_UNTIED}
 
 
@@ -244,6 +249,16 @@ def overwrite_row(model_dir: str, key: str, row: int, values: np.ndarray) -> np.
         f.seek(off + row * cols * esz)
         f.write(stored.contiguous().view(idt).numpy().tobytes())
     return stored.to(torch.float32).numpy()
+
+
+def overwrite_tensor(model_dir: str, key: str, values: np.ndarray) -> None:
+    """Overwrite a whole tensor in place (values rounded to the tensor's storage type)."""
+    path, e, off = _locate_tensor(model_dir, key)
+    tdt, idt, esz = _ST_DTYPES[e["dtype"]]
+    assert tuple(values.shape) == tuple(e["shape"])
+    with open(path, "r+b") as f:
+        f.seek(off)
+        f.write(torch.from_numpy(np.ascontiguousarray(values, dtype=np.float32)).to(tdt).contiguous().view(idt).numpy().tobytes())
 
 
 def output_embedding_key(model_dir: str) -> str:

@@ -28,3 +28,25 @@ def test_planted_checkpoint_stops_the_oracle_at_the_planned_steps(tmp_path):
     assert key == "thinker.lm_head.weight"
     row = synthetic.read_tensor(d, key)[synthetic.ENDOFTEXT_ID]
     assert abs(float(np.linalg.norm(row)) - info["row_norm"]) < 1e-3 * info["row_norm"]
+
+
+def test_peaked_fixture_walks_routes_and_stops_by_class(tmp_path):
+    """The round-4 fixture (peaked_checkpoint + plan_class_stops): the greedy successor of a token is walk_next, every length
+    class is routed down its own walk at step 0, the classes stop at their planted steps, and every step of every utterance
+    has a top-1/top-2 margin a bf16 engine can decide."""
+    from eos_plan import free_run_margins, peaked_checkpoint, plan_class_stops, walk_next
+    d = peaked_checkpoint(str(tmp_path / "peaked"), "tiny_untied", seed=5)
+    B, kmax = 14, 8
+    classes = [i % 7 for i in range(B)]
+    clips = [synthetic.synthetic_clip(200 + i, 1.0 + 0.35 * classes[i]) for i in range(B)]
+    class_stops = [1, None, 3, 5, 7, None, 2]
+    stops, routers, info = plan_class_stops(d, clips, classes, class_stops, kmax)
+    ids, margins = free_run_margins(d, clips, kmax)
+    V = 151936
+    for u in range(B):
+        k = classes[u]
+        assert len(ids[u]) == (kmax if class_stops[k] is None else class_stops[k])
+        assert ids[u][0] == routers[k]
+        assert all(ids[u][s] == walk_next(ids[u][s - 1], V) for s in range(1, len(ids[u])))
+        assert min(margins[u]) >= 1.0, (u, margins[u])
+    assert max(info["row_norms"]) < 200.0, info   # longer rows would amplify a bf16 engine's rounding noise beyond the margins

@@ -9,8 +9,9 @@ builds included).  Each test below therefore
   * measures the per-step max |logit error| against the oracle,
   * asserts exact ids on every over-margin step, counts the flips, and FAILS when more than MAX_UNDER_MARGIN of the
     steps are under the margin (the bound would otherwise be vacuous) or when any logit error exceeds the tolerance.
-With the synthetic (random-init) checkpoints the logits are nearly flat over 151 936 entries -- top-1/top-2 gaps of
-a few 1e-2 -- which is the hardest case for this criterion; real checkpoints are peaked.
+The checkpoints are the ones bench.py times: random-init with the token-embedding scale synthetic.PEAKED_EMBED_SCALE, at which
+the top-1/top-2 gaps are ~10x a bf16 engine's logit error (with the 0.02 of the golden fixtures the logits are nearly flat over
+151 936 entries and 7-15 % of the steps were undecidable; real checkpoints are peaked).
 
 Reference path: src/inference.rs:151-200 (greedy loop), run once per utterance.
 """
@@ -24,10 +25,10 @@ from qwen3_asr_rs_amd.engine import HipEngine
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = 0.05          # default-mode max |logit error| at 0.6B / 1.7B dims (|logit| <= ~3; measured 0.012-0.022)
+LOGIT_TOL = 0.10          # default-mode max |logit error| at 0.6B / 1.7B dims: 1.7 % of |logit| <= ~6 (round 3: 0.05 at |logit| <= 3; measured 0.4-0.8 %)
 EMBED_TOL = 2e-2          # rel-L2 of the audio embeddings
-MAX_UNDER_MARGIN = 0.20   # at most this fraction of the compared steps may sit inside the rounding noise (measured: <= 7 % over
-                          # 100 tokens at one clip, 9-14.5 % over 110 tokens at 32 clips -- nearly flat synthetic logits)
+MAX_UNDER_MARGIN = 0.10   # at most this fraction of the compared steps may sit inside the rounding noise (round 3: 0.20 with the
+                          # flat logits of embedding scale 0.02, measured 7-14.5 %; expected ~0 with PEAKED_EMBED_SCALE)
 MAX_FLIPS = 0.05          # fraction of steps whose greedy id may differ from the oracle's (each one justified, see margin_report)
 
 
@@ -87,7 +88,7 @@ def stepwise_logits(eng, prompts, forced, steps, keep=None):
 def test_config1_0p6b_one_clip_100_tokens_free_running():
     """BASELINE configs[1], exactly what bench.py times: 0.6B dims, ONE 30 s clip, default mode, 100 greedy tokens
     free-running from the graph-replayed decode loop."""
-    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b_peaked", "0.6b", seed=0, embed_scale=synthetic.PEAKED_EMBED_SCALE)
     clip = synthetic.synthetic_clip(0, 30.0)
     N = 100
     eng = HipEngine(d, 0, max_new_tokens=N)   # same cache capacity (hence key-split count) on both call paths
@@ -112,7 +113,7 @@ def test_config0_reference_clips_whole_path_0p6b_dims():
     import os
     from qwen3_asr_rs_amd.audio import load_audio
     golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test_audio")
-    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b_peaked", "0.6b", seed=0, embed_scale=synthetic.PEAKED_EMBED_SCALE)
     clips = [load_audio(os.path.join(golden, f"sample{i}.wav"), 16000) for i in (1, 2, 3)]
     assert [len(c) for c in clips] == [128000, 66560, 89600]
     N = 16
@@ -180,22 +181,21 @@ def test_config2_0p6b_batch32_30s_default_mode():
     margin-aware exact ids; every utterance's eager decode must equal the graph-replayed one.  110 free-running tokens:
     the context grows from 405 to 515 keys, so the batched decode attention crosses the 128-key tile boundaries at 512
     and the decode step is compared over more steps than bench.py times (100)."""
-    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b_peaked", "0.6b", seed=0, embed_scale=synthetic.PEAKED_EMBED_SCALE)
     _batch_config_check("config2 0.6B B=32", d, 32, (0, 31), steps=110, free_tokens=110)
 
 
 def test_config3_1p7b_batch16_30s_default_mode_sharded():
     """BASELINE configs[3]: 1.7B dims (expected dims), sharded safetensors, 16 x 30 s clips, DEFAULT
     mode (K = 2048 / 6144 skinny GEMM and LDS-DMA GEMM shapes that the 0.6B checkpoints never reach); 110 free-running
-    tokens as above (context 405 -> 515 keys; the last utterance over all 110 steps, the first over 12 -- a 1.7B oracle step
-    costs three times a 0.6B one)."""
-    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b", "1.7b", seed=0, shards=2)
-    _batch_config_check("config3 1.7B B=16", d, 16, {15: 110, 0: 12}, steps=110, free_tokens=110)
+    tokens as above (context 405 -> 515 keys), the first and the last utterance over all 110 steps."""
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b_peaked", "1.7b", seed=0, shards=2, embed_scale=synthetic.PEAKED_EMBED_SCALE)
+    _batch_config_check("config3 1.7B B=16", d, 16, {15: 110, 0: 110}, steps=110, free_tokens=110)
 
 
 def test_1p7b_one_clip_default_mode_gemv_path():
     """1.7B dims at batch 1: the GEMV decode path at K = 2048 / 6144 in the default mode (bench.py --preset 1.7b)."""
-    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b", "1.7b", seed=0, shards=2)
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b_peaked", "1.7b", seed=0, shards=2, embed_scale=synthetic.PEAKED_EMBED_SCALE)
     clip = synthetic.synthetic_clip(3, 30.0)
     N = 12
     eng = HipEngine(d, 0, max_new_tokens=N)
@@ -214,7 +214,7 @@ def test_one_launch_qkv_projection_and_attention_inside_each_xcd():
     out, and the greedy ids must equal the separate launches' (the projection rows are bit-identical)."""
     from qwen3_asr_rs_amd import _lib
     lib = _lib.load()
-    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b_peaked", "0.6b", seed=0, embed_scale=synthetic.PEAKED_EMBED_SCALE)
     clip = synthetic.synthetic_clip(3, 30.0)
     ids = {}
     try:

@@ -427,7 +427,11 @@ def test_native_group_one_gpu_through_rccl(tiny_dir, monkeypatch):
     monkeypatch.setenv("Q3A_GROUP_FORCE_RCCL", "1")
     grp = HipGroup(tiny_dir, 1, max_new_tokens=8)
     assert grp.size == 1 and grp.used_rccl
+    st = grp.startup_seconds   # pinned pack -> async H2D -> ncclBroadcast -> engines, each timed (q3a_group_startup_seconds)
+    assert st["pack_s"] > 0 and st["upload_s"] > 0 and st["broadcast_s"] > 0 and st["engines_s"] > 0, st
     assert grp.transcribe_batch(clips, None, max_new=5, fixed_new_tokens=5) == ref
+    tm = grp.engine_timings(0)
+    assert tm["batch"] == 3 and tm["total_ms"] > 0, tm
     grp.close()
     monkeypatch.delenv("Q3A_GROUP_FORCE_RCCL")
     grp = HipGroup(tiny_dir, 1, max_new_tokens=8)

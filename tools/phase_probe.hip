@@ -39,6 +39,29 @@ const char* launch_qknorm_rope_kv(const RopeKvArgs&, int, bool, hipStream_t) { r
 
 typedef unsigned long long u64;
 
+// Experiment (Q3A_PROBE_KV_PREFETCH): pull the live cache rows of the NEXT layer's attention through the memory hierarchy (into
+// the 256 MiB Infinity Cache) from a parallel graph branch while the weight-streaming GEMMs -- which leave HBM mostly idle --
+// run.  `segs` segments of `seg_bytes` live bytes, `seg_stride` bytes apart; a workgroup walks its share with 16-B loads.
+__global__ __launch_bounds__(256) void kv_prefetch_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, size_t seg_bytes, size_t seg_stride,
+                                                          int segs, unsigned* sink) {
+  const size_t per = seg_bytes / 16;                       // uint4 per segment
+  const size_t total = per * segs;
+  uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256 * 4) {
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t j = std::min(i + (size_t)u * gridDim.x * 256, total - 1);
+      const size_t off = (j / per) * (seg_stride / 16) + (j % per);
+      v[2 * u] = a[off];
+      v[2 * u + 1] = b[off];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { acc.x ^= v[u].x; acc.y ^= v[u].y; acc.z ^= v[u].z; acc.w ^= v[u].w; }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) *sink = acc.x;  // (never: keeps the loads alive)
+}
+
 struct Launch { int kind; int wgs; size_t off; };  // stamp rows of one launch: [off, off + wgs)
 
 static void summarize(const char* title, const std::vector<const char*>& kind_names, const std::vector<std::vector<const char*>>& phase_names,
@@ -129,6 +152,26 @@ int main(int argc, char** argv) {
     CHK(hipMemset(stamps, 0, rows * 8 * sizeof(u64)));
     std::vector<Launch> ls;
     const int nparts = H / 8;
+    const char* pf_env = getenv("Q3A_PROBE_KV_PREFETCH");
+    const int pf_mode = pf_env ? atoi(pf_env) : 0;  // 0 off, 1 parallel graph branch under the GEMMs, 2 serial right before the attention (upper bound)
+    const char* pfw_env = getenv("Q3A_PROBE_KV_PREFETCH_WGS");
+    const int pf_wgs = pfw_env ? atoi(pfw_env) : 128;
+    hipStream_t side;
+    CHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    std::vector<hipEvent_t> evs;
+    auto new_ev = [&]() { hipEvent_t e; CHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); evs.push_back(e); return e; };
+    unsigned* sink;
+    CHK(hipMalloc(&sink, 64));
+    hipEvent_t pending = nullptr;  // prefetch of the coming layer's KV, issued behind the previous layer's attention
+    auto kv_of = [&](int idx, uint16_t*& kc, uint16_t*& vc) {
+      uint16_t* base = pool + (size_t)(idx % (2 * L)) * slab;
+      kc = base + e_qkv + e_o + e_gu + e_dn; vc = kc + e_kv;
+    };
+    auto prefetch = [&](int idx, hipStream_t st) {
+      uint16_t *kc, *vc;
+      kv_of(idx, kc, vc);
+      hipLaunchKernelGGL(kv_prefetch_kernel, dim3(pf_wgs), dim3(256), 0, st, (const uint4*)kc, (const uint4*)vc, (size_t)(POS + 1) * 256, (size_t)MAXCTX * 256, S * NKV, sink);
+    };
     auto layer = [&](int idx, bool record, bool stamped) {
       uint16_t* base = pool + (size_t)(idx % (2 * L)) * slab;
       const uint16_t *w_qkv = base, *w_o = w_qkv + e_qkv, *w_gu = w_o + e_o, *w_dn = w_gu + e_gu;
@@ -139,10 +182,20 @@ int main(int argc, char** argv) {
       q.x = x; q.ldx = H; q.S = S; q.eps = 1e-6f; q.W = w_qkv; q.N = QKV; q.K = H; q.xw16f = nn_x; q.ss_parts = nn_ss; q.ss_nparts = nparts;
       q.mode = 0; q.out = qkv; q.ldo = QKV; q.stamp = rec(0, wg_qkv);
       KCHK(q3a::launch_skinny(q, false, s));
+      if (pf_mode == 2) prefetch(idx, s);
+      if (pf_mode == 1 && pending) { CHK(hipStreamWaitEvent(s, pending, 0)); pending = nullptr; }  // join: this layer's KV has been pulled in
       q3a::DecodeAttnArgs da{};
       da.qkv = qkv; da.pos = pos; da.eps = 1e-6f; da.rope_cur = rope; da.q_norm = nw; da.k_norm = nw; da.kcache = kc; da.vcache = vc;
       da.n_q = NQ; da.n_kv = NKV; da.max_ctx = MAXCTX; da.scale_div = 11.3137f; da.out16 = ctx16; da.out_frag = 1; da.stamp = rec(1, wg_att);
       KCHK(q3a::launch_decode_attn_batched(da, S, false, s));
+      if (pf_mode == 1) {  // fork: the next layer's KV streams in on the side branch under o / gate-up / down / qkv
+        hipEvent_t f = new_ev(), j = new_ev();
+        CHK(hipEventRecord(f, s));
+        CHK(hipStreamWaitEvent(side, f, 0));
+        prefetch(idx + 1, side);
+        CHK(hipEventRecord(j, side));
+        pending = j;
+      }
       q3a::SkinnyArgs o{};
       o.x = reinterpret_cast<float*>(ctx16); o.x16 = ctx16; o.x16_frag = 1; o.ldx = QD; o.S = S; o.W = w_o; o.N = H; o.K = QD; o.mode = 1; o.out = x; o.ldo = H; o.resid = x;
       o.next_w = nw; o.next_xw16f = nn_x; o.next_ss = nn_ss; o.qsplit = 1; o.stamp = rec(2, wg_o);
@@ -161,6 +214,7 @@ int main(int argc, char** argv) {
       hipGraphExec_t ge;
       CHK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
       for (int i = 0; i < L * STEPS; ++i) layer(i, stamped == 1 && ls.size() < (size_t)5 * L * STEPS, stamped == 1);
+      if (pending) { CHK(hipStreamWaitEvent(s, pending, 0)); pending = nullptr; }
       CHK(hipStreamEndCapture(s, &g));
       CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
       hipEvent_t a, b;
@@ -172,7 +226,7 @@ int main(int argc, char** argv) {
         CHK(hipEventRecord(a, s)); CHK(hipGraphLaunch(ge, s)); CHK(hipEventRecord(b, s)); CHK(hipStreamSynchronize(s));
         float ms; CHK(hipEventElapsedTime(&ms, a, b)); best = std::min(best, ms);
       }
-      printf("batched decode layer (32 seq x %d keys, 0.6B dims), %s: %.2f us per layer (%.1f us per 28-layer step)\n", POS + 1,
+      printf("[kv prefetch mode %d, %d workgroups] batched decode layer (32 seq x %d keys, 0.6B dims), %s: %.2f us per layer (%.1f us per 28-layer step)\n", pf_mode, pf_wgs, POS + 1,
              stamped ? "stamped build, stamps on" : "stamped build, stamps off (null pointer)", best * 1e3 / (L * STEPS), best * 1e3 / STEPS);
       CHK(hipGraphExecDestroy(ge)); CHK(hipGraphDestroy(g));
       if (stamped) {
