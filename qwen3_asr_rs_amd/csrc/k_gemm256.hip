@@ -70,29 +70,39 @@ struct ConvA256 {
   const uint16_t* x;
   const uint16_t* zero;  // >= 128 B of zeros for padded taps and for the half tile past K (K % 64 == 32)
   int H, W, C, OH, OW;
-  struct Row { long base; int ih0, iw0, chunk; };  // base: element offset of (img, ih0, iw0, channel 0) -- may point before a row
+  // Per staged row (fixed for the whole tile): byte address of (img, ih0, iw0, channel chunk) -- may point in front of an image
+  // row -- and a 9-bit mask of the filter taps that fall inside the image, so that the per-K-tile work of a lane is one shift +
+  // one 64-bit add + one select (the round-3 form recomputed ih / iw and five comparisons per staging instruction: ~20 VALU
+  // instructions x 4 per K tile and wave next to 64 MFMAs; profiles/r4_conv_loader.txt).
+  struct Row { const uint16_t* p; const uint16_t* z; unsigned taps; int hb; };
   __device__ __forceinline__ Row init(int m, int M, int chunk) const {
     if (m >= M) m = M - 1;
     const int img = m / (OH * OW);
     const int r = m - img * OH * OW;
     const int oh = r / OW, ow = r - oh * OW;
     const int ih0 = oh * 2 - 1, iw0 = ow * 2 - 1;
-    return Row{(((long)img * H + ih0) * W + iw0) * C, ih0, iw0, chunk};
+    unsigned taps = 0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+        if (ih0 + kh >= 0 && ih0 + kh < H && iw0 + kw >= 0 && iw0 + kw < W) taps |= 1u << (kh * 3 + kw);
+    const int sub = (chunk & 3) * 8;
+    return Row{x + ((((long)img * H + ih0) * W + iw0) * C + sub), zero + sub, taps, chunk >= 4 ? 1 : 0};
   }
-  struct KIter { int kh, kw, c0; };  // filter tap and first channel of a 32-wide half (wave-uniform: scalar registers)
-  __device__ __forceinline__ KIter kbegin() const { return KIter{0, 0, 0}; }
+  struct KIter { int tap, off; };  // filter tap (kh * 3 + kw; 9 = past K) and element offset (kh * W + kw) * C + c0 of a 32-wide half (scalar registers)
+  __device__ __forceinline__ KIter kbegin() const { return KIter{0, 0}; }
   __device__ __forceinline__ void knext(KIter& k) const {
-    k.c0 += 32;
-    if (k.c0 >= C) { k.c0 = 0; if (++k.kw == 3) { k.kw = 0; ++k.kh; } }
+    k.off += 32;
+    const int c_end = ((k.tap / 3) * W + (k.tap % 3)) * C + C;  // first offset past this tap's channels
+    if (k.off >= c_end) {
+      ++k.tap;
+      k.off = ((k.tap / 3) * W + (k.tap % 3)) * C;
+    }
   }
   __device__ __forceinline__ const uint16_t* src(const Row& r, const KIter& ka, const KIter& kb) const {
-    const bool hb = r.chunk >= 4;  // this lane's half of the tile
-    const int kh = hb ? kb.kh : ka.kh, kw = hb ? kb.kw : ka.kw;
-    const int toff = hb ? (kb.kh * W + kb.kw) * C + kb.c0 : (ka.kh * W + ka.kw) * C + ka.c0;  // scalar products, one select
-    const int ih = r.ih0 + kh, iw = r.iw0 + kw;
-    const bool ok = kh < 3 && ih >= 0 && ih < H && iw >= 0 && iw < W;  // kh == 3: the zero half tile past K = 9 * C
-    const int sub = (r.chunk & 3) * 8;
-    return ok ? x + (r.base + toff + sub) : zero + sub;
+    const int tap = r.hb ? kb.tap : ka.tap, off = r.hb ? kb.off : ka.off;
+    return ((r.taps >> tap) & 1u) ? r.p + off : r.z;  // tap == 9 (the zero half tile past K = 9 * C): bit 9 is never set
   }
 };
 

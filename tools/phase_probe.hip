@@ -110,6 +110,7 @@ static void summarize(const char* title, const std::vector<const char*>& kind_na
 int main(int argc, char** argv) {
   const bool do_layer = argc < 2 || strstr(argv[1], "layer"), do_gemm = argc < 2 || strstr(argv[1], "gemm"), do_one = argc < 2 || strstr(argv[1], "one");
   const bool do_small = argc < 2 || strstr(argv[1], "small");
+  const bool do_conv = argc >= 2 && strstr(argv[1], "conv");
   hipStream_t s;
   CHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   KCHK(q3a::skinny_init());
@@ -381,6 +382,58 @@ int main(int argc, char** argv) {
       if (first_round)
         printf("    mean per tile (first round): prologue %.2f  K-loop %.2f  stage0 %.2f  store0 %.2f  stage1 %.2f  store1 %.2f\n", ph_first[0] / first_round,
                ph_first[1] / first_round, ph_first[2] / first_round, ph_first[3] / first_round, ph_first[4] / first_round, ph_first[5] / first_round);
+    }
+  }
+  if (do_conv) {
+    // ---------------- part 3: conv2 / conv3 as implicit GEMM (ConvA256 loader) next to a DENSE GEMM of the same M x N x K ----------------
+    // 8 clips' worth of chunks (240): conv2 M = 240 * 32 * 25 = 192 000 output positions, N = 480, K = 9 * 480
+    struct CShape { const char* name; int imgs, H, W; };
+    const CShape cs[] = {{"conv2 (64 x 50 -> 32 x 25)", 240, 64, 50}, {"conv3 (32 x 25 -> 16 x 13)", 240, 32, 25}};
+    const int C = 480;
+    uint16_t* X = pool;                       // NHWC input map / dense A
+    uint16_t* W = pool + ((size_t)5 << 28);   // weights 2.5 GiB further on
+    uint16_t* zero;
+    CHK(hipMalloc(&zero, 256)); CHK(hipMemset(zero, 0, 256));
+    float* bias;
+    uint16_t* out16;
+    CHK(hipMalloc(&out16, (size_t)192000 * 480 * 2)); CHK(hipMalloc(&bias, 8192 * 4)); CHK(hipMemset(bias, 0, 8192 * 4));
+    u64* stamps;
+    const int max_tiles = 2048;
+    CHK(hipMalloc(&stamps, (size_t)max_tiles * 8 * sizeof(u64)));
+    q3a::knobs().gemm256_min_tiles = 0;
+    setenv("Q3A_GEMM256_SPLIT_REM", "0", 1);
+    for (const CShape& c : cs) {
+      const int OH = (c.H - 1) / 2 + 1, OW = (c.W - 1) / 2 + 1, M = c.imgs * OH * OW, K = 9 * C, N = C;
+      const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+      for (int dense = 0; dense < 2; ++dense) {
+        q3a::GemmEpilogue ep;
+        ep.ldo = N; ep.bias = bias; ep.out16 = out16; ep.act = 1;
+        hipEvent_t a, b;
+        CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+        float best = 1e30f;
+        for (int r = 0; r < 6; ++r) {
+          ep.stamp = (r == 5) ? stamps : nullptr;
+          if (r == 5) CHK(hipMemsetAsync(stamps, 0, (size_t)max_tiles * 8 * sizeof(u64), s));
+          CHK(hipEventRecord(a, s));
+          if (dense) KCHK(q3a::launch_gemm256(X, (K + 63) / 64 * 64, W, M, N, (K + 63) / 64 * 64, ep, false, s));
+          else KCHK(q3a::launch_conv3x3s2_gemm256(X, zero, c.imgs, c.H, c.W, C, W, N, ep, s));
+          CHK(hipEventRecord(b, s));
+          CHK(hipStreamSynchronize(s));
+          float ms; CHK(hipEventElapsedTime(&ms, a, b));
+          if (r > 0 && r < 5) best = std::min(best, ms);
+        }
+        const double tf = 2.0 * M * N * K / (best * 1e-3) * 1e-12;
+        printf("\n%s %s: M %d N %d K %d, %d tiles (%.2f rounds of 256), %.1f us, %.0f TFLOP/s\n", c.name, dense ? "as a DENSE GEMM of the same size" : "implicit GEMM (ConvA256)", M, N, K, tiles,
+               tiles / 256.0, best * 1e3, tf);
+        std::vector<u64> h((size_t)max_tiles * 8);
+        CHK(hipMemcpy(h.data(), stamps, h.size() * sizeof(u64), hipMemcpyDeviceToHost));
+        double ph[6] = {0, 0, 0, 0, 0, 0};
+        const int nt = std::min(tiles, max_tiles);
+        for (int w = 0; w < nt; ++w)
+          for (int q = 0; q < 6; ++q) ph[q] += (double)(h[w * 8 + q + 1] - h[w * 8 + q]) * 0.01;
+        printf("    mean per tile: prologue %.2f  K-loop %.2f (%.3f per K tile)  stage0 %.2f  store0 %.2f  stage1 %.2f  store1 %.2f  (us; wave 0 of the tile)\n", ph[0] / nt, ph[1] / nt,
+               ph[1] / nt / ((K + 63) / 64), ph[2] / nt, ph[3] / nt, ph[4] / nt, ph[5] / nt);
+      }
     }
   }
   if (do_small) {
