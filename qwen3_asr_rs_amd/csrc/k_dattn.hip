@@ -745,10 +745,13 @@ const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f
   dim3 grid(a.n_kv, S), block(DA_WAVES * 64);
   // A/B knob Q3A_DATTN_TILE64=1: 64-key tiles with a 4-deep register ring (same bytes in flight, steadier request stream)
   static const bool tile64 = [] { const char* e = getenv("Q3A_DATTN_TILE64"); return e && atoi(e) != 0; }();
+  // A/B knob Q3A_DATTN_RING4=1: four 128-key tiles in flight per wave (every key of a <= 512-key context requested up front)
+  static const bool ring4 = [] { const char* e = getenv("Q3A_DATTN_RING4"); return e && atoi(e) != 0; }();
 #define Q3A_DAB(G)                                                                                          \
   do {                                                                                                      \
     if (kv_f32) hipLaunchKernelGGL((decode_attn_batched_kernel<G, float>), grid, block, 0, s, a);          \
     else if (tile64) hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t, 64, 4>), grid, block, 0, s, a); \
+    else if (ring4) hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t, 128, 4>), grid, block, 0, s, a); \
     else hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t>), grid, block, 0, s, a);              \
   } while (0)
   if (group == 1) Q3A_DAB(1);
