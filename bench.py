@@ -144,7 +144,8 @@ def kernel_trace(inner_args, timeout_s=420, warmup=0, steps=1) -> dict:
         for k, durs in per.items():
             drop = (len(durs) * warmup) // max(warmup + steps, 1) if len(durs) >= warmup + steps else 0
             kept = durs[drop:]
-            res[k] = {"calls": len(kept), "total_us": float(sum(kept)), "avg_us": float(sum(kept)) / len(kept)}
+            res[k] = {"calls": len(kept), "total_us": float(sum(kept)), "avg_us": float(sum(kept)) / len(kept),
+                      "warmup_avg_us": (float(sum(durs[:drop])) / drop) if drop else None}
         return res
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
@@ -550,11 +551,19 @@ def main():
         inner = ["--preset", args.preset, "--batch", str(B), "--seconds", str(args.seconds)] + (["--precise"] if args.precise else []) \
             + (["--ckpt-dir", args.ckpt_dir] if args.ckpt_dir else [])
         # ---- dominant kernel, in situ ----
-        trace, trace_err, dom = None, None, None
+        trace, trace_err, dom, dom_runs = None, None, None, []
         if world == 1 and not args.no_rocprof:
             try:
-                trace = kernel_trace(inner + ["--new-tokens", str(args.new_tokens), "--steps", "3", "--warmup", "1"], warmup=1, steps=3)
+                # The first profiled process on a fresh box runs the same kernels 5-8 % slower than the third (profiles/
+                # r4_trace_warmup_note.txt: 5.00 / 4.64 / 4.64 us for the dominant GEMV in three consecutive child runs, 12 warm-up
+                # passes inside the first one change nothing), while the un-profiled timed region above is warm: the child is
+                # run three times, the LAST run is reported and all three averages of the dominant kernel are kept in the line.
+                trace_runs = []
+                for _ in range(3):
+                    trace = kernel_trace(inner + ["--new-tokens", str(args.new_tokens), "--steps", "3", "--warmup", "1"], warmup=1, steps=3)
+                    trace_runs.append(trace)
                 dom = max(trace.items(), key=lambda kv: kv[1]["total_us"])
+                dom_runs = [round(t[dom[0]]["avg_us"], 3) for t in trace_runs if dom[0] in t]
                 if args.trace_out:
                     tot = sum(v["total_us"] for v in trace.values())
                     with open(args.trace_out, "w") as f:
@@ -573,8 +582,9 @@ def main():
             roof.update(kernel=kshort + " (decode qkv + gate/up GEMV)", bytes_per_launch=round(ab["qkv_gateup_gemv_per_launch"]),
                         avg_launch_us=round(kinfo["avg_us"], 3), launches_traced=kinfo["calls"],
                         share_of_kernel_time=round(kinfo["total_us"] / sum(v["total_us"] for v in trace.values()), 4),
-                        avg_launch_us_source="rocprofv3 --kernel-trace --stats, child run of this workload (1 warm-up pass left out + 3 timed graph-replayed passes), in situ",
-                        launches_per_token=2 * dims.dec_layers)
+                        avg_launch_us_source="rocprofv3 --kernel-trace --stats, child run of this workload (1 warm-up pass left out + 3 timed graph-replayed passes), in situ; "
+                                             "third of three consecutive child runs (the first profiled process on a fresh box is 5-8 % slower)",
+                        avg_launch_us_of_the_three_child_runs=dom_runs, launches_per_token=2 * dims.dec_layers)
         elif dom is not None:
             # batched configurations: report the dominant kernel's name/time; its algorithmic bytes are per-step figures
             kshort, kinfo = dom
