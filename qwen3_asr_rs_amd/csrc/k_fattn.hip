@@ -459,7 +459,10 @@ __global__ __launch_bounds__(256, NS == 3 ? 3 : 2) void fattn_dma_kernel(AttnArg
     tr_reads(0);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      if (rescale) oacc[dt] *= alpha;
+      if (rescale) {
+        asm volatile("" ::: "memory");  // keeps this a BRANCH: hipcc if-converts the bare form into 64 multiplies + 64 v_cndmask per tile
+        oacc[dt] *= alpha;
+      }
       // the wait statement takes tile dt's registers as in/out operands: the MFMAs below depend on IT, not on the reads (hipcc
       // assumes an asm's outputs are ready when the asm has been issued and would hoist the MFMAs above a bare wait)
       if (dt + 1 < DT) {
