@@ -160,16 +160,28 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfrag[ks], sacc, 0, 0, 0);
     }
     // lane owns query qi and keys key0 + (r&3) + 8*(r>>2) + 4*half
+    // (round 4, as in fattn_dma_kernel below: no masking on tiles that lie wholly in front of the wave's first query, and the
+    // running output is rescaled only when some query of the wave saw a new maximum)
+    const bool full = key0 + 31 <= (CAUSAL ? min(q0, seg.len - 1) : seg.len - 1);  // wave-uniform
     float tmax = -INFINITY;
+    if (full) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const bool valid = key < seg.len && (!CAUSAL || key <= qi);
-      sacc[r] = valid ? sacc[r] * inv_scale : -INFINITY;
-      tmax = fmaxf(tmax, sacc[r]);
+      for (int r = 0; r < 16; ++r) {
+        sacc[r] *= inv_scale;
+        tmax = fmaxf(tmax, sacc[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool valid = key < seg.len && (!CAUSAL || key <= qi);
+        sacc[r] = valid ? sacc[r] * inv_scale : -INFINITY;
+        tmax = fmaxf(tmax, sacc[r]);
+      }
     }
     tmax = xor32_max(tmax);
     const float m_new = fmaxf(mrun, tmax);
+    const bool rescale = __builtin_amdgcn_ballot_w64(m_new > mrun) != 0;
     float alpha = 1.f, psum = 0.f;
     if (m_new == -INFINITY) {  // nothing visible yet for this query (only for padding queries)
 #pragma unroll
@@ -197,7 +209,10 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
     // ---- O^T[d][query] = alpha * O^T + sum_key V[key][d] P[key][query] ----
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      oacc[dt] *= alpha;  // vector op: packed multiplies
+      if (rescale) {
+        asm volatile("" ::: "memory");  // keeps this a branch (hipcc if-converts the bare form into 64 multiplies + 64 selects)
+        oacc[dt] *= alpha;  // vector op: packed multiplies
+      }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         // contraction slot (half, e) <-> key 16*kk + 4*half + (e & 3) + 8*(e >> 2): same map as the P registers
