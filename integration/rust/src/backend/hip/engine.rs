@@ -38,6 +38,7 @@ extern "C" {
     pub fn q3a_group_destroy(g: *mut q3a_group);
     pub fn q3a_group_size(g: *const q3a_group) -> i32;
     pub fn q3a_group_last_error(g: *const q3a_group) -> *const c_char;
+    pub fn q3a_group_startup_seconds(g: *const q3a_group, out4: *mut f64) -> i32;
     pub fn q3a_group_transcribe(g: *mut q3a_group, pcm16k: *const f32, n_samples: *const i64, b: i32, lang_prefix_ids: *const i32,
                                 n_prefix: i32, max_new: i32, fixed_new_tokens: i32, out_ids: *mut i32, stride: i32, out_lens: *mut i32) -> i32;
 }
@@ -99,6 +100,13 @@ impl HipGroup {
         let rc = unsafe { q3a_group_create(dir.as_ptr(), n_gpus as i32, std::ptr::null(), std::ptr::null(), &mut raw) };
         if rc != 0 { bail!("Failed to load model: {}", msg(unsafe { q3a_last_error(std::ptr::null()) })); }
         Ok(HipGroup { raw })
+    }
+
+    /// Start-up stage times in seconds: [checkpoint read + pack into pinned memory, H2D upload, RCCL broadcast, engine creation].
+    pub fn startup_seconds(&self) -> [f64; 4] {
+        let mut v = [0f64; 4];
+        unsafe { q3a_group_startup_seconds(self.raw, v.as_mut_ptr()) };
+        v
     }
 
     pub fn transcribe_batch(&self, clips: &[&[f32]], lang_prefix_ids: &[i32], max_new: usize) -> Result<Vec<Vec<i64>>> {
