@@ -203,12 +203,12 @@ def test_output_parsing_mirror():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r3_bench_final.json is the bench.py line of this round: every field the driver and the judge read
+    """profiles/r4_bench_final.json is the bench.py line of this round: every field the driver and the judge read
     must be there with the right type (BASELINE.json metric, roofline and cpu_baseline objects), the roofline must come
     from the in-situ trace and be internally consistent, and the extra legs must name BASELINE.json's other configs."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    j = json.load(open(os.path.join(root, "profiles", "r3_bench_final.json")))
+    j = json.load(open(os.path.join(root, "profiles", "r4_bench_final.json")))
     base = json.load(open(os.path.join(root, "BASELINE.json")))
     assert j["metric"].split(",")[0] == base["metric"].split(",")[0]
     assert j["unit"] == "audio-seconds/sec" and j["higher_is_better"] is True and j["scaling"] == "weak"
@@ -229,9 +229,42 @@ def test_committed_bench_line_follows_the_contract():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and len(c["runs"]) >= 5
     ne = j["natural_eos"]  # the reference's contract (fixed_new_tokens = 0) beside the fixed-N number, BASELINE.md section 3
     assert ne["stopped_at_planned_token"] is True and ne["generated_tokens"] == j["config"]["new_tokens"]
-    assert 0 < ne["value"] <= j["value"] * 1.02 and ne["decode_steps_executed"] - ne["decode_steps_needed"] <= 2
+    assert 0 < ne["value"] <= j["value"] * 1.02 and ne["decode_steps_executed"] == ne["decode_steps_needed"]   # run-ahead 1: no step past the EOS
+    assert j["two_streams"]["ids_equal_to_one_engine"] is True
+    runs = r["avg_launch_us_of_the_three_child_runs"]   # the reported in-situ average is the LAST of three profiled child runs
+    assert len(runs) == 3 and abs(runs[-1] - r["avg_launch_us"]) < 1e-3
     ex = j["extra"]
     assert len(ex) == 2 and "batch=32" in ex[0]["workload"] and "1.7b" in ex[1]["workload"] and all(e["value"] > 0 for e in ex)
+
+
+def test_bench_kernel_trace_leaves_the_warmup_pass_out(tmp_path, monkeypatch):
+    """bench.kernel_trace: per kernel, the dispatches of the warm-up passes (the first warmup / (warmup + steps) by start time) are
+    dropped from the in-situ statistics, as the bench's own timed region drops its warm-up steps (no rocprofv3, no GPU: a rocpd-shaped
+    SQLite file stands in for the child's trace)."""
+    import sqlite3
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    out = tmp_path / "prof"
+    out.mkdir()
+    db = sqlite3.connect(str(out / "x_results.db"))
+    db.execute("create table kernels (name text, start integer, end integer)")
+    t = 0
+    for p in range(4):                       # 1 warm-up + 3 timed passes of 5 launches each; the warm-up pass is 1000 ns slower
+        for i in range(5):
+            dur = 5000 + (1000 if p == 0 else 0)
+            db.execute("insert into kernels values (?, ?, ?)", ("void q3a::(anonymous namespace)::gemv1_kernel<2, 2, true, false>(q3a::GemvArgs)", t, t + dur))
+            t += dur + 1500
+        db.execute("insert into kernels values (?, ?, ?)", ("void q3a::(anonymous namespace)::mel_kernel(q3a::MelBatch)", t, t + 200000))  # once per pass
+        t += 201500
+    db.commit(); db.close()
+    monkeypatch.setattr(bench, "_rocprof", lambda extra, inner, timeout: (str(out / "x_results.db"), str(out)))
+    res = bench.kernel_trace(["--steps", "3", "--warmup", "1"], warmup=1, steps=3)
+    g = next(v for k, v in res.items() if k.startswith("gemv1_kernel"))
+    assert g["calls"] == 15 and abs(g["avg_us"] - 5.0) < 1e-9 and abs(g["warmup_avg_us"] - 6.0) < 1e-9
+    m = next(v for k, v in res.items() if k.startswith("mel_kernel"))
+    assert m["calls"] == 3 and abs(m["avg_us"] - 200.0) < 1e-9
 
 
 def test_bench_n_gpu_launch_path_without_a_gpu():
