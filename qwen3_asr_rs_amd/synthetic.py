@@ -153,6 +153,9 @@ def write_checkpoint(model_dir: str, preset: str = "tiny", seed: int = 0, shards
     if os.path.exists(done):
         return model_dir
     os.makedirs(model_dir, exist_ok=True)
+    for stale in os.listdir(model_dir):  # another variant (seed / scale / dtype ...) was written here before: its marker must not outlive its weights
+        if stale.startswith(".complete."):
+            os.remove(os.path.join(model_dir, stale))
     with open(os.path.join(model_dir, "config.json"), "w") as f:
         json.dump({"thinker_config": cfg}, f, indent=1)
     gen = torch.Generator().manual_seed(seed)
