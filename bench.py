@@ -14,7 +14,8 @@ Launching.  N = 1: `python bench.py`.  N > 1: one process per GPU under torch.di
 a bare `python bench.py --gpus N` re-executes itself under torch.distributed.run on 127.0.0.1 with a free port, so the
 same command shape works at every N.  With N > 1 the line also carries an `extra` leg: BASELINE configs[4]'s per-GPU
 workload (Qwen3-ASR-1.7B, 32 clips per GPU, weights shipped with ONE RCCL broadcast of the arena); the q3a_group_* leg (on by default; --no-native-group-leg) adds
-the native q3a_group_* path (one process, one host thread per GPU, RCCL called from C++).
+the native q3a_group_* path (one process, one host thread per GPU, RCCL called from C++), run as a child process with a time limit so
+that neither a crash nor a hang inside it can cost the line.
 
 What is inside the clock
   value               PCM already resident in HBM when the clock starts (the task contract), generated ids fetched to the
@@ -418,6 +419,37 @@ def native_group_leg(preset, ckpt_dir, world, B, seconds, new_tokens, steps, pre
     return out
 
 
+def native_group_child(args, world, B, timeout_s=600):
+    """The q3a_group_* leg in a process of its own (`bench.py --inner-group`), bounded by a timeout: this path has never met a
+    multi-GPU box, and neither a crash nor a hang inside it may cost the bench line.  Returns the leg's record or an error record."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--inner-group", "--gpus", str(world), "--batch", str(B), "--preset", args.preset,
+           "--seconds", str(args.seconds), "--new-tokens", str(args.new_tokens), "--steps", str(args.steps)] \
+        + (["--precise"] if args.precise else []) + (["--ckpt-dir", args.ckpt_dir] if args.ckpt_dir else [])
+    rec = {"workload": "q3a_group_transcribe", "value": None}
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)  # on timeout: kills this child only
+    except subprocess.TimeoutExpired:
+        return dict(rec, error=f"no result within {timeout_s} s (child killed)")
+    for line in reversed(r.stdout.splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return dict(rec, error=f"rc={r.returncode}: {(r.stderr or r.stdout)[-300:]}")
+
+
+def inner_group_main(args):
+    """Child of native_group_child: one JSON line on stdout."""
+    try:
+        out = native_group_leg(args.preset, args.ckpt_dir, args.gpus, args.batch, args.seconds, args.new_tokens, args.steps, args.precise)
+    except Exception as ex:  # noqa: BLE001
+        out = {"workload": "q3a_group_transcribe", "value": None, "error": str(ex)[:300]}
+    print(json.dumps(out), flush=True)
+
+
 def extra_leg(preset, B, seconds, new_tokens, steps, warmup, precise):
     """One more single-GPU workload of BASELINE.json `configs` timed the same way (PCM resident, ids fetched)."""
     from qwen3_asr_rs_amd import synthetic
@@ -459,6 +491,7 @@ def main():
     ap.add_argument("--ckpt-dir", default=None)
     ap.add_argument("--trace-out", default=None, help="write the per-kernel table of the in-situ rocprofv3 kernel trace to this file")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--inner-group", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--launch-check", action="store_true",
                     help="only exercise the N > 1 launch path (self re-launch, rendezvous, barrier, max over ranks) on the gloo backend: no GPU needed")
     args = ap.parse_args()
@@ -470,6 +503,8 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     if args.inner:
         return inner_main(args)
+    if args.inner_group:
+        return inner_group_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -539,10 +574,7 @@ def main():
             # that no collective kernel of theirs spins on the GPUs meanwhile
             cpu_pg = dist.new_group(backend="gloo")
             if rank == 0:
-                try:
-                    multi_extra.append(native_group_leg(args.preset, args.ckpt_dir, world, B, args.seconds, args.new_tokens, args.steps, args.precise))
-                except Exception as ex:  # noqa: BLE001
-                    multi_extra.append({"workload": "q3a_group_transcribe", "value": None, "error": str(ex)[:300]})
+                multi_extra.append(native_group_child(args, world, B))
             dist.barrier(group=cpu_pg)
 
     if rank == 0:

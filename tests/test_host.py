@@ -285,3 +285,23 @@ def test_bench_n_gpu_launch_path_without_a_gpu():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)["launch_check"]
     assert j == {"world": 2, "max_over_ranks": 2, "master_addr": "127.0.0.1"}
+
+
+def test_bench_native_group_leg_is_a_bounded_child(monkeypatch):
+    """The q3a_group_* leg of `bench.py --gpus N` runs in a child process: a child that dies (here: no HIP device) or does not answer
+    within the timeout (here: a sleeping stand-in) yields an error record for the JSON line, never an exception or a hang."""
+    import argparse, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    args = argparse.Namespace(preset="0.6b", seconds=30.0, new_tokens=100, steps=2, precise=False, ckpt_dir=None)
+    if not torch.cuda.is_available():
+        rec = bench.native_group_child(args, 2, 1, timeout_s=240)
+        assert rec["value"] is None and "HIP device" in rec["error"], rec
+    real_run = subprocess.run
+    monkeypatch.setattr(bench.subprocess, "run", lambda cmd, **kw: real_run([sys.executable, "-c", "import time; time.sleep(60)"], **kw))
+    t0 = time.time()
+    rec = bench.native_group_child(args, 2, 1, timeout_s=2)
+    assert rec["value"] is None and "no result within 2 s" in rec["error"] and time.time() - t0 < 30, rec
+    monkeypatch.setattr(bench.subprocess, "run", lambda cmd, **kw: real_run([sys.executable, "-c", "print('noise'); print('{\"workload\": \"q3a_group_transcribe\", \"value\": 7.0}')"], **kw))
+    assert bench.native_group_child(args, 2, 1)["value"] == 7.0
