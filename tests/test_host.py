@@ -231,8 +231,9 @@ def test_committed_bench_line_follows_the_contract():
     assert ne["stopped_at_planned_token"] is True and ne["generated_tokens"] == j["config"]["new_tokens"]
     assert 0 < ne["value"] <= j["value"] * 1.02 and ne["decode_steps_executed"] == ne["decode_steps_needed"]   # run-ahead 1: no step past the EOS
     assert j["two_streams"]["ids_equal_to_one_engine"] is True
-    runs = r["avg_launch_us_of_the_three_child_runs"]   # the reported in-situ average is the LAST of three profiled child runs
-    assert len(runs) == 3 and abs(runs[-1] - r["avg_launch_us"]) < 1e-3
+    runs = r["avg_launch_us_of_the_three_child_runs"]   # the reported in-situ average is the MEDIAN of three profiled child runs
+    assert len(runs) == 3 and abs(sorted(runs)[1] - r["avg_launch_us"]) < 1e-3
+    assert abs(ne["vs_fixed_n_ms"] - (ne["ms_per_step"] - ne["fixed_n_same_engine_ms"])) < 2e-3   # paired on one engine
     ex = j["extra"]
     assert len(ex) == 2 and "batch=32" in ex[0]["workload"] and "1.7b" in ex[1]["workload"] and all(e["value"] > 0 for e in ex)
 
