@@ -115,7 +115,7 @@ if twice:
                 print(f"      {name} execution elem {j} (lane {l}): got {fw[j]:.7f} expected {exp[j]:.7f}; implied operand {imp:.6f}; "
                       f"closest candidate {best} = {cand[best]:.6f}; all: " + ", ".join(f"{k}={v:.5f}" for k, v in cand.items()), flush=True)
 print(f"SOAK{(' ' + args.tag) if args.tag else ''}: {events} event(s) ({id_events} with differing ids) in {done} runs of {B} clips, {args.load} load engine(s), "
-      f"{dt:.1f} s, solo repeats differing {solo_bad}, ring={os.environ.get('Q3A_GEMM16_RING', '0')} rope_variant={os.environ.get('Q3A_ROPE_VARIANT', '0')} "
+      f"{dt:.1f} s, solo repeats differing {solo_bad}, ring={os.environ.get('Q3A_GEMM16_RING', 'default(1)')} rope_variant={os.environ.get('Q3A_ROPE_VARIANT', '0')} "
       f"split_rem={os.environ.get('Q3A_GEMM256_SPLIT_REM', 'default')} lib={os.path.basename(os.environ.get('Q3A_LIB', 'libq3asr_hip.so'))}"
       + (f" rope_twice mismatching vectors {mism}" if twice else ""), flush=True)
 A.close()
