@@ -258,6 +258,9 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *                        one barrier per K tile.  (Round 3 kept this off because it raised the rate of a rare run-to-run difference
  *                        with several engines busy on one GPU; that was the packed-fp32 op_sel hazard of csrc/dev.h, which the
  *                        library no longer contains -- DESIGN.md section 8.)
+ *   "gemm256_resid_prefetch"  1 (default): the fp32-residual epilogue of the 256x256 GEMM (o / down / fc2 / out projections at
+ *                        batch-sized row counts) requests the 16 residual rows of a 64-row pass before staging the pass; 0: the
+ *                        loads sit inside the store loop, four dependent round trips per pass (A/B).  Same arithmetic either way.
  *   "rope_variant"       hazard-isolation builds only (-DQ3A_ROPE_EXPERIMENT, never the product library): arithmetic form of
  *                        qknorm_rope_kv_kernel (csrc/dev.h head_norm_rope; tools/soak_engines.py).  Ignored by the product library.
  *   "rope_twice"         debug, 0 (default) / 1: batch-sized prefills execute the trailing rows' rope kernel a second time into

@@ -112,6 +112,7 @@ Knobs& knobs() {
     env("Q3A_EOS_RUN_AHEAD", k.eos_run_ahead);
     env("Q3A_LIVE_KEY_SPLITS", k.live_key_splits);
     env("Q3A_GEMM16_RING", k.gemm16_ring);
+    env("Q3A_GEMM256_RESID_PREFETCH", k.gemm256_resid_prefetch);
     env("Q3A_ROPE_VARIANT", k.rope_variant);
     env("Q3A_DEBUG_ROPE_TWICE", k.rope_twice);
   });
@@ -1558,6 +1559,7 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (strcmp(key, "eos_run_ahead") == 0) { kn.eos_run_ahead = value; return 0; }
   if (strcmp(key, "live_key_splits") == 0) { kn.live_key_splits = value; return 0; }
   if (strcmp(key, "gemm16_ring") == 0) { kn.gemm16_ring = value; return 0; }
+  if (strcmp(key, "gemm256_resid_prefetch") == 0) { kn.gemm256_resid_prefetch = value; return 0; }
   if (strcmp(key, "rope_variant") == 0) { kn.rope_variant = value; return 0; }
   if (strcmp(key, "rope_twice") == 0) { kn.rope_twice = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";

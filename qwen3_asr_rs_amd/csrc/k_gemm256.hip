@@ -123,7 +123,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 template <bool GLU, class ALoader, bool ROPE = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16_t* __restrict__ Wt,
                                                          const uint16_t* __restrict__ zero, int M, int N, int K, GemmEpilogue ep,
-                                                         RopeKvArgs rk) {
+                                                         RopeKvArgs rk, int resid_prefetch) {
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * G_BUF];  // the ONLY LDS object of this kernel
 
   Q3A_STAMP_AT(ep.stamp, blockIdx.x, 0);  // entry
@@ -318,6 +318,65 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
   float* stg = reinterpret_cast<float*>(lds + wave * 16384);  // [64][64] fp32
   const int col_in = lane & 15, row_in = (lane >> 4) * 4;
   const bool wide16 = (N % 8 == 0) && (ep.ldo % 8 == 0);  // bf16 rows that can be written 16 B per lane (kernel-uniform)
+  if constexpr (!GLU && !ROPE) {
+    // fp32 residual output, nothing else in the epilogue (x += X.W^T + b: o / down / fc2 / out projections).  The general store
+    // loop below asks for a residual row inside the iteration that needs it -- one exposed round trip per 4 rows, 11.7 us per
+    // 64-row pass in the stamped timeline (profiles/r3_phase_probe_after_*.txt: 131 KiB read + 131 KiB written per CU at
+    // 22 GB/s) next to 16.6 us of K loop at K = 896.  Here the 16 residual rows of a pass are requested back to back: pass 0's as
+    // soon as pass 0's accumulators are staged (their registers take the rows), so pass 1 never waits for its rows and pass 0
+    // waits for one round trip, row by row (counted vmcnt).  Addresses = wave-uniform row base + ONE per-lane byte offset.  M % 4 == 0: the 4 rows of an
+    // iteration are inside or outside the matrix together.  Same arithmetic ((acc + bias) + residual).  Knob: gemm256_resid_prefetch.
+    if (ep.resid != nullptr && ep.out16 == nullptr && ep.rowmap == nullptr && ep.addend == nullptr && ep.act == 0 && (M & 3) == 0 &&
+        resid_prefetch != 0) {  // kernel-uniform
+      const int n = n0 + wc * 64 + (lane & 15) * 4;
+      const unsigned voff = ((unsigned)(lane >> 4) * (unsigned)ep.ldo + (unsigned)(n < N ? n : 0)) * 4u;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ep.bias && n < N) bv = *reinterpret_cast<const float4*>(ep.bias + n);
+      float4 rpre[2][16];
+      auto request = [&](int h) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int rb = m0 + wr * 128 + h * 64 + it * 4;
+          const char* base = reinterpret_cast<const char*>(ep.resid) + (size_t)(rb < M ? rb : 0) * ep.ldo * 4;  // outside: a valid row, never stored
+          rpre[h][it] = *reinterpret_cast<const float4*>(base + voff);
+        }
+      };
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) stg[(i * 16 + row_in + r) * 64 + j * 16 + col_in] = acc[h * 4 + i][j][r];
+        if (h == 0) {
+          // the bias row (requested above, before the staging) must be in registers BEFORE the 32 requests: hipcc sinks its load
+          // behind them otherwise, and the first row's wait for it becomes a wait for all 33
+          asm volatile("" : "+v"(bv.x), "+v"(bv.y), "+v"(bv.z), "+v"(bv.w));
+          request(0);
+          request(1);  // 32 loads back to back; vmcnt is counted per row below
+        }
+        Q3A_STAMP_AT(ep.stamp, blockIdx.x, 3 + h * 2);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // 4 rows of LDS reads at a time (the fence keeps the other 12 from being hoisted into registers)
+#pragma unroll
+          for (int it = g * 4; it < g * 4 + 4; ++it) {
+            float4 v = *reinterpret_cast<const float4*>(&stg[(it * 4 + (lane >> 4)) * 64 + (lane & 15) * 4]);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            const float4 b = rpre[h][it];
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));  // unconditional: or hipcc sinks row, adds AND the row's load into the store's branch
+            const int rb = m0 + wr * 128 + h * 64 + it * 4;
+            char* base = reinterpret_cast<char*>(ep.out) + (size_t)rb * ep.ldo * 4;
+            if (rb < M && n < N) *reinterpret_cast<float4*>(base + voff) = v;
+          }
+          asm volatile("" ::: "memory");
+        }
+        Q3A_STAMP_AT(ep.stamp, blockIdx.x, 4 + h * 2);
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -373,29 +432,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
         posv[it] = rk.row_pos[mc];
         seqv[it] = is_q ? 0 : rk.row_seq[mc];
       }
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      // cos / sin rows one iteration ahead (two register sets): inside the iteration that uses them the four loads were an exposed
+      // round trip each time -- 8 per pass, 16 per tile (ISA: global_load x4 ... s_waitcnt vmcnt(0) in every iteration)
+      const bool roped = is_q || is_k;  // wave-uniform
+      float4 rc0[2], rc1[2], rs0[2], rs1[2];
+      auto rope_rows = [&](int it) {
+        const float* cp = rk.cos_t + (size_t)posv[it] * 64 + c8;
+        const float* sp = rk.sin_t + (size_t)posv[it] * 64 + c8;
+        rc0[it & 1] = *reinterpret_cast<const float4*>(cp); rc1[it & 1] = *reinterpret_cast<const float4*>(cp + 4);
+        rs0[it & 1] = *reinterpret_cast<const float4*>(sp); rs1[it & 1] = *reinterpret_cast<const float4*>(sp + 4);
+      };
+      // one straight-line loop per kind of wave (q / k: rotated; v: copied): with the requests under a condition hipcc's wait
+      // counting falls back to vmcnt(0) in front of every use, i.e. waits for the rows just requested as well
+      auto body = [&](auto roped_c, int it) {
+        constexpr bool RP = decltype(roped_c)::value;
         const int row = it * 8 + (lane >> 3), m = mrow0 + row;
         const int pos = posv[it];
         float xo[8], xp[8];
         {
           const float4 o0 = *reinterpret_cast<const float4*>(&stg[row * 64 + c8]), o1 = *reinterpret_cast<const float4*>(&stg[row * 64 + c8 + 4]);
-          const float4 p0 = *reinterpret_cast<const float4*>(&pst[row * 64 + c8]), p1 = *reinterpret_cast<const float4*>(&pst[row * 64 + c8 + 4]);
           xo[0] = o0.x; xo[1] = o0.y; xo[2] = o0.z; xo[3] = o0.w; xo[4] = o1.x; xo[5] = o1.y; xo[6] = o1.z; xo[7] = o1.w;
-          xp[0] = p0.x; xp[1] = p0.y; xp[2] = p0.z; xp[3] = p0.w; xp[4] = p1.x; xp[5] = p1.y; xp[6] = p1.z; xp[7] = p1.w;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { xo[e] += b_own[e]; xp[e] += b_par[e]; }
+        for (int e = 0; e < 8; ++e) xo[e] += b_own[e];
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = xo[e];
-        if (is_q || is_k) {  // wave-uniform
+        if constexpr (RP) {
+          {
+            const float4 p0 = *reinterpret_cast<const float4*>(&pst[row * 64 + c8]), p1 = *reinterpret_cast<const float4*>(&pst[row * 64 + c8 + 4]);
+            xp[0] = p0.x; xp[1] = p0.y; xp[2] = p0.z; xp[3] = p0.w; xp[4] = p1.x; xp[5] = p1.y; xp[6] = p1.z; xp[7] = p1.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xp[e] += b_par[e];
           float cs[8], sn[8];
           {
-            const float* cp = rk.cos_t + (size_t)pos * 64 + c8;
-            const float* sp = rk.sin_t + (size_t)pos * 64 + c8;
-            const float4 c0 = *reinterpret_cast<const float4*>(cp), c1 = *reinterpret_cast<const float4*>(cp + 4);
-            const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+            const float4 c0 = rc0[it & 1], c1 = rc1[it & 1], s0 = rs0[it & 1], s1 = rs1[it & 1];
             cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
             sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
           }
@@ -412,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
             v[e] = no * cs[e] + np * sn[e];
           }
         }
-        if (m >= M || ncol >= N) continue;
+        if (m >= M || ncol >= N) return;
         uint4 pk;
         pk.x = pack_bf16x2(v[0], v[1]); pk.y = pack_bf16x2(v[2], v[3]); pk.z = pack_bf16x2(v[4], v[5]); pk.w = pack_bf16x2(v[6], v[7]);
         if (is_q) {
@@ -423,6 +495,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
                         (((size_t)seqv[it] * rk.n_kv + kvh) * rk.max_ctx + pos) * 128 + d_own;
           *reinterpret_cast<uint4*>(c) = pk;
         }
+      };
+      if (roped) {
+        rope_rows(0);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          if (it + 1 < 8) rope_rows(it + 1);
+          asm volatile("" ::: "memory");  // the requests stay here: hipcc would sink them to their use in the next iteration
+          body(std::true_type{}, it);
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) body(std::false_type{}, it);
       }
       __syncthreads();  // the partner is done with this wave's staged half before the next pass overwrites it
     } else if (!GLU && ep.out16 && wide16) {
@@ -559,7 +643,8 @@ template <bool GLU, class ALoader, bool ROPE = false>
 void launch256(const ALoader& A, const uint16_t* W, const uint16_t* zero, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s,
                const RopeKvArgs& rk = RopeKvArgs{}) {
   const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-  hipLaunchKernelGGL((gemm256_kernel<GLU, ALoader, ROPE>), dim3(tiles), dim3(512), 0, s, A, W, zero, M, N, K, ep, rk);
+  hipLaunchKernelGGL((gemm256_kernel<GLU, ALoader, ROPE>), dim3(tiles), dim3(512), 0, s, A, W, zero, M, N, K, ep, rk,
+                     knobs().gemm256_resid_prefetch.load(std::memory_order_relaxed));
 }
 
 }  // namespace

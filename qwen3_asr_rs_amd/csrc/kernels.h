@@ -67,6 +67,7 @@ struct Knobs {
   std::atomic<int> gemm16_ring{1};              // Q3A_GEMM16_RING: 3-4-stage LDS rings with counted vmcnt in the small-M GEMMs (0: two stages, one barrier per K tile)
   std::atomic<int> rope_variant{0};             // Q3A_ROPE_VARIANT (experiment): arithmetic form of qknorm_rope_kv_kernel (dev.h head_norm_rope)
   std::atomic<int> rope_twice{0};               // Q3A_DEBUG_ROPE_TWICE (debug): re-execute the trailing rows' rope kernel into shadow buffers and compare
+  std::atomic<int> gemm256_resid_prefetch{1};   // Q3A_GEMM256_RESID_PREFETCH: fp32-residual epilogue of gemm256 requests a pass's 16 residual rows ahead of staging it (0: four dependent round trips inside the store loop)
   std::atomic<int> live_key_splits{1};          // Q3A_LIVE_KEY_SPLITS: one-sequence decode attention launches the key splits the caches HOLD keys for (0: as many as they have room for)
 };
 Knobs& knobs();

@@ -342,6 +342,7 @@ int main(int argc, char** argv) {
     const int max_tiles = 1024;
     CHK(hipMalloc(&stamps, (size_t)max_tiles * 8 * sizeof(u64)));
     q3a::knobs().gemm256_min_tiles = 0;
+    if (const char* e = getenv("Q3A_GEMM256_RESID_PREFETCH")) q3a::knobs().gemm256_resid_prefetch = atoi(e);  // A/B of the residual epilogue
     setenv("Q3A_GEMM256_SPLIT_REM", "0", 1);  // every tile in ONE gemm256 launch: the phase means are per tile of that launch
     for (const Shape& sh : shapes) {
       const int tiles = ((sh.M + 255) / 256) * ((sh.N + 255) / 256);
