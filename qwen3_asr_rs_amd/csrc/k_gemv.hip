@@ -123,6 +123,12 @@ __device__ __forceinline__ void attn_merge8_ch(const GemvArgs& a, int b, int k, 
       o0[j] = *reinterpret_cast<const float4*>(a.attn_po + (size_t)(base + spc) * 128 + d);
       o1[j] = *reinterpret_cast<const float4*>(a.attn_po + (size_t)(base + spc) * 128 + d + 4);
     }
+    // every request above stays above: without the fence hipcc sinks the l / o loads below the `continue` that only needs m --
+    // m first, a wait, then the rest: two dependent round trips where the source has one (ISA: global_load x5, s_waitcnt
+    // vmcnt(0), branch, global_load x21)
+#ifndef Q3A_NO_MERGE_FENCE  // A/B builds only
+    asm volatile("" ::: "memory");
+#endif
     float Mn = M;
 #pragma unroll
     for (int j = 0; j < CH; ++j) Mn = fmaxf(Mn, m[j]);
