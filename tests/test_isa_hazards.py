@@ -31,3 +31,32 @@ def test_product_device_code_has_no_packed_fp32_op_sel():
     # the scan really reads kernels: the rope kernel is in there, written with single VALU instructions
     txt = open(build.isa_path("k_decode.hip")).read()
     assert "qknorm_rope_kv_kernel" in txt and "v_pk_mul_f32" not in txt.split("qknorm_rope_kv_kernel")[1].split("s_endpgm")[0]
+
+
+def test_batched_requests_stay_batched_in_the_device_code():
+    """Performance structure that hipcc undid once already (tools/isa_waits.py reads the kept assembly):
+      * gemm256's fp32-residual epilogue requests the 32 residual rows of a tile back to back (before: one `s_waitcnt vmcnt(0)`
+        behind each of them -- 16 exposed round trips per 64-row pass);
+      * the o_proj GEMV's split merge requests m, l and the partial outputs of a chunk in one batch (hipcc sank l / o below the branch
+        that only needs m);
+      * the decode qkv / gate-up GEMV requests its whole weight stream before the first wait.
+    No GPU: the assembly is what `python -m qwen3_asr_rs_amd.build` keeps."""
+    import importlib.util
+    import re
+    build.build(verbose=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("isa_waits", os.path.join(root, "tools", "isa_waits.py"))
+    iw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(iw)
+    ks = {k: iw.compress(iw.tokens(b)) for _, k, b in iw.kernels()}
+    assert len(ks) > 100
+
+    def longest_load_run(pattern):
+        name = [k for k in ks if re.search(pattern, k)]
+        assert len(name) == 1, (pattern, name)
+        return max([int(n or 1) for n in re.findall(r"\bG(?:x(\d+))?\b", ks[name[0]])] or [0])
+
+    assert longest_load_run(r"gemm256_kernelILb0ENS0_9DenseA256ELb0EEE") >= 30      # 32 residual rows (hipcc may move one or two)
+    assert longest_load_run(r"gemv1_kernelILi1ELi4ELb0ELb1EEE") >= 26               # merge: 4 x (m, l, o0, o1) + ... in one batch
+    assert longest_load_run(r"gemv1_kernelILi2ELi2ELb1ELb0EEE") >= 12               # qkv / gate-up: x, norm weight and the weight rows
+    assert iw.exposed(["G", "W0", "j", "G", "G", "W0", "G", "G", "G", "W0"]) == 2   # the suspects metric itself
