@@ -19,17 +19,27 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
   const float* xr = x + (size_t)row * D;
   float* yr = y + (size_t)row * D;
   const int nv = D / 4;  // float4 count
-  float4 v[MAX_V];
+  // Every load of the row, of the weight and of the bias is requested before anything is used, from clamped (always valid)
+  // addresses; lanes beyond the row are voided arithmetically.  With `if (c < nv) { load; use }` hipcc put every load into an
+  // exec-masked block of its own with s_waitcnt vmcnt(0) behind it: 8 dependent round trips per row where one is enough -- 5 us per
+  // launch at one clip, where a wave has its SIMD to itself and nothing hides them (profiles/r4_isa_wait_audit.txt).
+  const int nit = (nv + 63) >> 6;  // wave-uniform: iterations that hold a column at all
+  float4 v[MAX_V], wv[MAX_V], bv[MAX_V];
+#pragma unroll
+  for (int i = 0; i < MAX_V; ++i) {
+    v[i] = wv[i] = bv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < nit) {
+      const int c = lane + i * 64, cc = c < nv ? c : nv - 1;
+      v[i] = reinterpret_cast<const float4*>(xr)[cc];
+      wv[i] = reinterpret_cast<const float4*>(w)[cc];
+      if (LN) bv[i] = reinterpret_cast<const float4*>(b)[cc];
+    }
+  }
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < MAX_V; ++i) {
-    const int c = lane + i * 64;
-    if (c < nv) {
-      v[i] = reinterpret_cast<const float4*>(xr)[c];
-      sum += LN ? (v[i].x + v[i].y + v[i].z + v[i].w) : (v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w);
-    } else {
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    if (lane + i * 64 >= nv) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // a select, not a branch
+    sum += LN ? (v[i].x + v[i].y + v[i].z + v[i].w) : (v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w);
   }
   sum = wave_sum(sum);
   float mean = 0.f, rstd;
@@ -38,11 +48,9 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
     float var = 0.f;
 #pragma unroll
     for (int i = 0; i < MAX_V; ++i) {
-      const int c = lane + i * 64;
-      if (c < nv) {
-        const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
-        var += a * a + bb * bb + cc * cc + dd * dd;
-      }
+      const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+      const float q = a * a + bb * bb + cc * cc + dd * dd;
+      var += (lane + i * 64 < nv) ? q : 0.f;
     }
     var = wave_sum(var) / (float)D;
     rstd = 1.0f / sqrtf(var + eps);
@@ -52,21 +60,19 @@ __global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ x, 
 #pragma unroll
   for (int i = 0; i < MAX_V; ++i) {
     const int c = lane + i * 64;
+    float4 o;
+    if (LN) {
+      o.x = (v[i].x - mean) * rstd * wv[i].x + bv[i].x;
+      o.y = (v[i].y - mean) * rstd * wv[i].y + bv[i].y;
+      o.z = (v[i].z - mean) * rstd * wv[i].z + bv[i].z;
+      o.w = (v[i].w - mean) * rstd * wv[i].w + bv[i].w;
+    } else {
+      o.x = (v[i].x * rstd) * wv[i].x;
+      o.y = (v[i].y * rstd) * wv[i].y;
+      o.z = (v[i].z * rstd) * wv[i].z;
+      o.w = (v[i].w * rstd) * wv[i].w;
+    }
     if (c < nv) {
-      const float4 wv = reinterpret_cast<const float4*>(w)[c];
-      float4 o;
-      if (LN) {
-        const float4 bv = reinterpret_cast<const float4*>(b)[c];
-        o.x = (v[i].x - mean) * rstd * wv.x + bv.x;
-        o.y = (v[i].y - mean) * rstd * wv.y + bv.y;
-        o.z = (v[i].z - mean) * rstd * wv.z + bv.z;
-        o.w = (v[i].w - mean) * rstd * wv.w + bv.w;
-      } else {
-        o.x = (v[i].x * rstd) * wv.x;
-        o.y = (v[i].y * rstd) * wv.y;
-        o.z = (v[i].z * rstd) * wv.z;
-        o.w = (v[i].w * rstd) * wv.w;
-      }
       if (y16) {  // default mode: bf16 copy for the next GEMM's LDS-DMA
         uint2 pk;
         pk.x = pack_bf16x2(o.x, o.y);
