@@ -217,11 +217,24 @@ def timed_region(eng, clips, steps, warmup, new_tokens, sync_all):
 
 
 def host_to_host(eng, clips, steps, new_tokens):
+    """SURVEY.md section 8d's window: host PCM (one pageable numpy array per clip) -> ids on the host, one
+    q3a_transcribe_batch_ptrs call per step.  Returns (elapsed seconds, input-side timings of the last call)."""
     eng.transcribe_batch(clips, None, max_new=new_tokens, fixed_new_tokens=new_tokens)
     t0 = time.perf_counter()
     for _ in range(steps):
-        eng.transcribe_batch(clips, None, max_new=new_tokens, fixed_new_tokens=new_tokens)
-    return time.perf_counter() - t0
+        ids = eng.transcribe_batch(clips, None, max_new=new_tokens, fixed_new_tokens=new_tokens)
+    elapsed = time.perf_counter() - t0
+    assert len(ids) == len(clips) and all(len(x) == new_tokens for x in ids)
+    io = eng.io_timings()
+    return elapsed, {"stage_ms": round(io["stage_ms"], 3), "h2d_ms": round(io["h2d_ms"], 3), "pieces": io["pieces"], "host_copy_threads": io["threads"]}
+
+
+def h2h_record(B, seconds, steps, h2h, io, resident_ms):
+    ms = h2h / steps * 1e3
+    return {"value": round(B * seconds * steps / h2h, 3), "ms_per_step": round(ms, 3),
+            "vs_pcm_resident_pct": round(100.0 * (ms - resident_ms) / resident_ms, 2), "input": io,
+            "what": "q3a_transcribe_batch_ptrs on rank 0: host PCM (pageable, one buffer per clip) -> pinned staging by host threads -> "
+                    "H2D in pieces on a copy stream, log-mel of a piece under the next piece's copy -> hot path -> ids on the host"}
 
 
 def inner_main(args):
@@ -471,11 +484,13 @@ def extra_leg(preset, B, seconds, new_tokens, steps, warmup, precise):
     P = int(stage["total_prompt_tokens"]) // B
     ab = algorithmic_bytes(eng.dims, B, P, new_tokens)
     dec_us = stage["decode_ms"] * 1e3 / max(int(stage["decode_steps"]), 1)
+    h2h, h2h_io = host_to_host(eng, clips, steps, new_tokens)  # SURVEY.md section 8d's window for this workload too
     eng.close()
     return {"workload": f"Qwen3-ASR-{preset} bf16, batch={B} x {seconds:.0f}s clips, 1 GPU, {new_tokens} new tokens (fixed)",
             "value": round(B * seconds * steps / elapsed, 3), "unit": "audio-seconds/sec", "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3),
             "stage_ms": {k: round(float(v), 3) for k, v in stage.items() if k.endswith("_ms")},
+            "host_to_host": h2h_record(B, seconds, steps, h2h, h2h_io, elapsed / steps * 1e3),
             "decode_stage": {"us_per_step": round(dec_us, 2), "bytes_per_step": round(ab["decode_per_step"]),
                              "achieved_GBps": round(ab["decode_per_step"] / dec_us / 1e3, 1),
                              "frac_of_hbm_peak": round(ab["decode_per_step"] / dec_us / 1e3 / HBM_PEAK_GBPS, 4)},
@@ -564,7 +579,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage = eng.timings()
-    h2h = host_to_host(eng, clips, args.steps, args.new_tokens) if rank == 0 else None
+    h2h, h2h_io = host_to_host(eng, clips, args.steps, args.new_tokens) if rank == 0 else (None, None)
     gemv_path = B <= 2
     stream_prof = eng.profile_weight_stream(reps=4) if gemv_path else None  # back-to-back microbenchmark
     dims = eng.dims
@@ -691,8 +706,7 @@ def main():
                        "timed_window": "PCM resident in HBM -> generated ids on the host",
                        "parallelism": f"dp{world} (independent utterances per GPU, no data-path collective)"},
             "stage_ms": {k: round(float(v), 3) for k, v in stage.items() if k.endswith("_ms")},
-            "host_to_host": {"value": round(B * args.seconds * args.steps / h2h, 3), "ms_per_step": round(h2h / args.steps * 1e3, 3),
-                             "what": "q3a_transcribe_batch on rank 0: host PCM -> H2D -> hot path -> ids on the host"},
+            "host_to_host": h2h_record(B, args.seconds, args.steps, h2h, h2h_io, elapsed / args.steps * 1e3),
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -135,10 +135,27 @@ int32_t q3a_run_resident(q3a_engine* e, const int32_t* lang_prefix_ids, int32_t 
  * as generated_ids in src/inference.rs:167). */
 int32_t q3a_fetch_ids(q3a_engine* e, int32_t* out_ids, int32_t stride, int32_t* out_lens);
 
-/* upload + run + fetch. */
+/* upload + run + fetch: AsrInference::transcribe steps 2-8 (src/inference.rs:95-200) for B utterances, host PCM in,
+ * generated ids on the host out -- the window SURVEY.md section 8d times.  The input copy is overlapped with the front
+ * end: the (pageable) caller buffers are copied by a few host threads into a pinned mirror of the device layout and shipped
+ * in pieces on a copy stream; the log-mel kernel of a piece's utterances runs as soon as that piece has landed. */
 int32_t q3a_transcribe_batch(q3a_engine* e, const float* pcm16k, const int64_t* n_samples, int32_t B,
                              const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new,
                              int32_t fixed_new_tokens, int32_t* out_ids, int32_t stride, int32_t* out_lens);
+/* The same with one pointer per utterance (pcm16k[b] -> n_samples[b] floats): what a caller that decoded B files into B
+ * buffers has (src/audio.rs:7 returns one Vec<f32> per file) -- no concatenation on the host. */
+int32_t q3a_transcribe_batch_ptrs(q3a_engine* e, const float* const* pcm16k, const int64_t* n_samples, int32_t B,
+                                  const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new,
+                                  int32_t fixed_new_tokens, int32_t* out_ids, int32_t stride, int32_t* out_lens);
+/* Where the input side of the last q3a_transcribe_batch[_ptrs] call spent its time. */
+typedef struct q3a_io_timings {
+  float stage_ms; /* host clock: entry -> last piece copied to pinned memory and its H2D copy + log-mel enqueued */
+  float h2d_ms;   /* hipEvents on the copy stream: first piece issued -> last piece landed */
+  float wall_ms;  /* host clock of the whole call (upload + hot path + ids on the host) */
+  int32_t pieces, threads; /* H2D pieces (runs of utterances) and host copy threads used */
+  int32_t mode;   /* 1: staged + overlapped (default); 0: Q3A_UPLOAD_MODE=0, one pageable copy per utterance on the compute stream */
+} q3a_io_timings;
+int32_t q3a_io_timings_last(const q3a_engine* e, q3a_io_timings* out);
 
 /* ---- multi-GPU: one process, one host thread per GPU ------------------------------------ */
 /* The reference is single-device (src/main.rs:51-65 picks ONE device); a batch of independent utterances is new
@@ -163,6 +180,10 @@ void q3a_group_partition(int32_t n_items, int32_t world_size, int32_t rank, int3
 int32_t q3a_group_transcribe(q3a_group* g, const float* pcm16k, const int64_t* n_samples, int32_t B,
                              const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new, int32_t fixed_new_tokens,
                              int32_t* out_ids, int32_t stride, int32_t* out_lens);
+/* The same with one pointer per utterance (see q3a_transcribe_batch_ptrs). */
+int32_t q3a_group_transcribe_ptrs(q3a_group* g, const float* const* pcm16k, const int64_t* n_samples, int32_t B,
+                                  const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new, int32_t fixed_new_tokens,
+                                  int32_t* out_ids, int32_t stride, int32_t* out_lens);
 
 /* ---- measurement ---------------------------------------------------------------------------------- */
 

@@ -14,12 +14,12 @@ SYMBOLS = [
     "q3a_opts_default", "q3a_device_count", "q3a_engine_create", "q3a_arena_bytes", "q3a_arena_pack", "q3a_engine_create_from_arena",
     "q3a_engine_destroy", "q3a_last_error", "q3a_get_dims", "q3a_weights_rounded", "q3a_num_frames", "q3a_num_audio_tokens",
     "q3a_build_prompt", "q3a_mel", "q3a_encode", "q3a_prefill", "q3a_decode_step", "q3a_set_next_tokens",
-    "q3a_upload_pcm", "q3a_run_resident", "q3a_fetch_ids", "q3a_transcribe_batch", "q3a_stage_timings",
+    "q3a_upload_pcm", "q3a_run_resident", "q3a_fetch_ids", "q3a_transcribe_batch", "q3a_transcribe_batch_ptrs", "q3a_io_timings_last", "q3a_stage_timings",
     "q3a_profile_decode_step", "q3a_profile_weight_stream", "q3a_debug_read", "q3a_debug_set", "q3a_selftest_gemm", "q3a_selftest_gemm16",
     "q3a_load_audio", "q3a_resample", "q3a_resample_rubato", "q3a_free", "q3a_tokenizer_create", "q3a_tokenizer_destroy",
     "q3a_tokenizer_decode", "q3a_tokenizer_encode", "q3a_normalize_nfc", "q3a_parse_asr_output", "q3a_capitalize_first",
     "q3a_group_create", "q3a_group_destroy", "q3a_group_size", "q3a_group_used_rccl", "q3a_group_last_error",
-    "q3a_group_engine", "q3a_group_partition", "q3a_group_transcribe", "q3a_group_startup_seconds",
+    "q3a_group_engine", "q3a_group_partition", "q3a_group_transcribe", "q3a_group_transcribe_ptrs", "q3a_group_startup_seconds",
 ]
 
 
@@ -40,6 +40,11 @@ class Timings(C.Structure):
     _fields_ = [("mel_ms", C.c_float), ("encoder_ms", C.c_float), ("prefill_ms", C.c_float), ("decode_ms", C.c_float),
                 ("total_ms", C.c_float), ("decode_steps", C.c_int32), ("batch", C.c_int32),
                 ("total_audio_tokens", C.c_int32), ("total_prompt_tokens", C.c_int32)]
+
+
+class IoTimings(C.Structure):
+    _fields_ = [("stage_ms", C.c_float), ("h2d_ms", C.c_float), ("wall_ms", C.c_float), ("pieces", C.c_int32), ("threads", C.c_int32),
+                ("mode", C.c_int32)]
 
 
 KC_NAMES = ["gemv_qkv_gateup", "decode_attn", "argmax", "gemm", "norm", "other", "gemv_o_proj", "gemv_down", "gemv_lm_head"]
@@ -86,6 +91,8 @@ def load() -> C.CDLL:
         "q3a_run_resident": (i32, [P, i32p, i32, i32, i32]),
         "q3a_fetch_ids": (i32, [P, i32p, i32, i32p]),
         "q3a_transcribe_batch": (i32, [P, f32p, i64p, i32, i32p, i32, i32, i32, i32p, i32, i32p]),
+        "q3a_transcribe_batch_ptrs": (i32, [P, C.POINTER(P), i64p, i32, i32p, i32, i32, i32, i32p, i32, i32p]),
+        "q3a_io_timings_last": (i32, [P, C.POINTER(IoTimings)]),
         "q3a_stage_timings": (i32, [P, C.POINTER(Timings)]),
         "q3a_profile_decode_step": (i32, [P, C.POINTER(KernelProfile)]),
         "q3a_profile_weight_stream": (i32, [P, i32, f32p, C.POINTER(C.c_double), i32p]),
@@ -113,6 +120,7 @@ def load() -> C.CDLL:
         "q3a_group_engine": (P, [P, i32]),
         "q3a_group_partition": (None, [i32, i32, i32, i32p, i32p]),
         "q3a_group_transcribe": (i32, [P, f32p, i64p, i32, i32p, i32, i32, i32, i32p, i32, i32p]),
+        "q3a_group_transcribe_ptrs": (i32, [P, C.POINTER(P), i64p, i32, i32p, i32, i32, i32, i32p, i32, i32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

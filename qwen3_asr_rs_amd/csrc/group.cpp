@@ -122,12 +122,28 @@ int32_t q3a_group_create(const char* model_dir, int32_t n_gpus, const int32_t* d
     g->engines.assign(n_gpus, nullptr);
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    // RAII for everything start-up creates besides the group's own members: an exception below (HIP, RCCL, a bad checkpoint)
+    // leaves no stream, communicator or pinned allocation behind
+    struct Stream {
+      int dev = 0;
+      hipStream_t s = nullptr;
+      ~Stream() { if (s) { (void)hipSetDevice(dev); (void)hipStreamDestroy(s); } }
+    };
     {  // the checkpoint is read ONCE (weights.rs:10-120) and packed straight into pinned host memory: the upload is one
-       // asynchronous DMA at PCIe rate instead of a pageable copy staged through the driver's bounce buffers
-      void* host = nullptr;
+       // asynchronous DMA at PCIe rate instead of a pageable copy staged through the driver's bounce buffers.  A host that
+       // refuses to pin the whole arena (1.6 / 4.1 GB; ulimit -l, cgroup limits) falls back to pageable memory + a blocking copy.
       GHIP(hipSetDevice(g->devices[0]));
-      GHIP(hipHostMalloc(&host, bytes, hipHostMallocDefault));
-      struct Pinned { void* p; ~Pinned() { if (p) (void)hipHostFree(p); } } pinned{host};
+      struct Pinned { void* p = nullptr; ~Pinned() { if (p) (void)hipHostFree(p); } } pinned;
+      std::vector<uint8_t> pageable;
+      void* host = nullptr;
+      if (hipHostMalloc(&pinned.p, bytes, hipHostMallocDefault) == hipSuccess && pinned.p) {
+        host = pinned.p;
+      } else {
+        (void)hipGetLastError();  // clear the sticky error of the failed allocation
+        pinned.p = nullptr;
+        pageable.resize(bytes);
+        host = pageable.data();
+      }
       const auto t0 = now();
       if (q3a_arena_pack(model_dir, host, bytes) != 0) fail(q3a_last_error(nullptr));
       const auto t1 = now();
@@ -136,11 +152,14 @@ int32_t q3a_group_create(const char* model_dir, int32_t n_gpus, const int32_t* d
         GHIP(hipMalloc(&g->arenas[i], bytes));
       }
       GHIP(hipSetDevice(g->devices[0]));
-      hipStream_t up = nullptr;
-      GHIP(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
-      GHIP(hipMemcpyAsync(g->arenas[0], host, bytes, hipMemcpyHostToDevice, up));
-      GHIP(hipStreamSynchronize(up));
-      GHIP(hipStreamDestroy(up));
+      if (pinned.p) {
+        Stream up{g->devices[0]};
+        GHIP(hipStreamCreateWithFlags(&up.s, hipStreamNonBlocking));
+        GHIP(hipMemcpyAsync(g->arenas[0], host, bytes, hipMemcpyHostToDevice, up.s));
+        GHIP(hipStreamSynchronize(up.s));
+      } else {
+        GHIP(hipMemcpy(g->arenas[0], host, bytes, hipMemcpyHostToDevice));
+      }
       g->startup_s[0] = secs(t0, t1);
       g->startup_s[1] = secs(t1, now());
     }
@@ -151,25 +170,37 @@ int32_t q3a_group_create(const char* model_dir, int32_t n_gpus, const int32_t* d
       const auto tb = now();
       Rccl r;
       r.load();
-      std::vector<ncclComm_t> comms(n_gpus, nullptr);
-      std::vector<hipStream_t> streams(n_gpus, nullptr);
-      r.check(r.CommInitAll(comms.data(), n_gpus, g->devices.data()), "ncclCommInitAll");
+      struct Comms {  // ncclCommInitAll creates all of them or none; destroyed on every way out
+        const Rccl& r;
+        std::vector<ncclComm_t> c;
+        ~Comms() { for (auto x : c) if (x) (void)r.CommDestroy(x); }
+      } comms{r, std::vector<ncclComm_t>(n_gpus, nullptr)};
+      std::vector<Stream> streams(n_gpus);
+      r.check(r.CommInitAll(comms.c.data(), n_gpus, g->devices.data()), "ncclCommInitAll");
       for (int i = 0; i < n_gpus; ++i) {
+        streams[i].dev = g->devices[i];
         GHIP(hipSetDevice(g->devices[i]));
-        GHIP(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking));
+        GHIP(hipStreamCreateWithFlags(&streams[i].s, hipStreamNonBlocking));
       }
       r.check(r.GroupStart(), "ncclGroupStart");
+      ncclResult_t first_bad = 0;
+      for (int i = 0; i < n_gpus; ++i) {
+        hipError_t he = hipSetDevice(g->devices[i]);
+        const ncclResult_t br = he == hipSuccess ? r.Broadcast(g->arenas[i], g->arenas[i], bytes, /*ncclUint8*/ 1, /*root*/ 0, comms.c[i], streams[i].s) : 1;
+        if (br != 0 && first_bad == 0) first_bad = br;  // (the group must still be closed before anything throws)
+      }
+      const ncclResult_t ge = r.GroupEnd();
+      r.check(first_bad, "ncclBroadcast");
+      r.check(ge, "ncclGroupEnd");
       for (int i = 0; i < n_gpus; ++i) {
         GHIP(hipSetDevice(g->devices[i]));
-        r.check(r.Broadcast(g->arenas[i], g->arenas[i], bytes, /*ncclUint8*/ 1, /*root*/ 0, comms[i], streams[i]), "ncclBroadcast");
+        GHIP(hipStreamSynchronize(streams[i].s));
       }
-      r.check(r.GroupEnd(), "ncclGroupEnd");
-      for (int i = 0; i < n_gpus; ++i) {
-        GHIP(hipSetDevice(g->devices[i]));
-        GHIP(hipStreamSynchronize(streams[i]));
-        GHIP(hipStreamDestroy(streams[i]));
+      for (auto& c : comms.c) {  // checked destroy on the normal path (the guard only covers what is left)
+        ncclComm_t x = c;
+        c = nullptr;
+        r.check(r.CommDestroy(x), "ncclCommDestroy");
       }
-      for (auto c : comms) r.check(r.CommDestroy(c), "ncclCommDestroy");
       g->used_rccl = true;
       g->startup_s[2] = secs(tb, now());
     }
@@ -201,14 +232,12 @@ q3a_engine* q3a_group_engine(q3a_group* g, int32_t rank) {
   return (g && rank >= 0 && rank < (int32_t)g->engines.size()) ? g->engines[rank] : nullptr;
 }
 
-int32_t q3a_group_transcribe(q3a_group* g, const float* pcm16k, const int64_t* n_samples, int32_t B,
-                             const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new, int32_t fixed_new_tokens,
-                             int32_t* out_ids, int32_t stride, int32_t* out_lens) {
+int32_t q3a_group_transcribe_ptrs(q3a_group* g, const float* const* pcm16k, const int64_t* n_samples, int32_t B,
+                                  const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new, int32_t fixed_new_tokens,
+                                  int32_t* out_ids, int32_t stride, int32_t* out_lens) {
   if (!g) return 1;
   if (!pcm16k || !n_samples || B < 1 || !out_ids || !out_lens || stride < 1) { g->err = "q3a_group_transcribe: bad argument"; return 1; }
   const int G = (int)g->engines.size();
-  std::vector<int64_t> pcm_off((size_t)B + 1, 0);
-  for (int b = 0; b < B; ++b) pcm_off[b + 1] = pcm_off[b] + n_samples[b];
   std::vector<std::string> errs(G);
   std::vector<std::thread> th;
   for (int r = 0; r < G; ++r) {
@@ -217,8 +246,8 @@ int32_t q3a_group_transcribe(q3a_group* g, const float* pcm16k, const int64_t* n
     if (b1 <= b0) continue;  // fewer utterances than GPUs
     th.emplace_back([=, &errs] {
       q3a_engine* e = g->engines[r];
-      if (q3a_transcribe_batch(e, pcm16k + pcm_off[b0], n_samples + b0, b1 - b0, lang_prefix_ids, n_prefix, max_new, fixed_new_tokens,
-                               out_ids + (size_t)b0 * stride, stride, out_lens + b0) != 0)
+      if (q3a_transcribe_batch_ptrs(e, pcm16k + b0, n_samples + b0, b1 - b0, lang_prefix_ids, n_prefix, max_new, fixed_new_tokens,
+                                    out_ids + (size_t)b0 * stride, stride, out_lens + b0) != 0)
         errs[r] = std::string("GPU ") + std::to_string(g->devices[r]) + ": " + q3a_last_error(e);
     });
   }
@@ -226,6 +255,17 @@ int32_t q3a_group_transcribe(q3a_group* g, const float* pcm16k, const int64_t* n
   for (auto& m : errs)
     if (!m.empty()) { g->err = m; return 1; }
   return 0;
+}
+
+int32_t q3a_group_transcribe(q3a_group* g, const float* pcm16k, const int64_t* n_samples, int32_t B,
+                             const int32_t* lang_prefix_ids, int32_t n_prefix, int32_t max_new, int32_t fixed_new_tokens,
+                             int32_t* out_ids, int32_t stride, int32_t* out_lens) {
+  if (!g) return 1;
+  if (!pcm16k || !n_samples || B < 1) { g->err = "q3a_group_transcribe: bad argument"; return 1; }
+  std::vector<const float*> ptrs((size_t)B);
+  int64_t off = 0;
+  for (int b = 0; b < B; ++b) { ptrs[b] = pcm16k + off; off += n_samples[b]; }
+  return q3a_group_transcribe_ptrs(g, ptrs.data(), n_samples, B, lang_prefix_ids, n_prefix, max_new, fixed_new_tokens, out_ids, stride, out_lens);
 }
 
 }  // extern "C"

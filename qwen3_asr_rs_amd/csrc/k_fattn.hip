@@ -531,6 +531,15 @@ static bool fattn_dma_on() {
   return on;
 }
 
+// What the LDS-DMA kernel assumes beyond the register-staged one: 16-byte global_load_lds sources (k / v base pointers, head and
+// row strides in whole 8-element groups) and bf16x8 q loads.  A caller that does not meet it gets the register-staged kernel,
+// not wrong data.  (AttnSeg::kv_off lives in device memory: multiples of 8 elements are the caller's contract -- the engine's
+// offsets are multiples of the row size, engine.cpp set_batch / setup_prompts.)
+static bool fattn_dma_ok(const AttnArgs& a) {
+  const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return fattn_dma_on() && a.q16 && al16(a.q16) && al16(a.k) && al16(a.v) && a.q_rs % 8 == 0 && a.kv_rs % 8 == 0 && a.kv_hs % 8 == 0;
+}
+
 template <int HD, int GROUP, bool CAUSAL, typename KVT, int KSPLIT = 1>
 void launch_f(const AttnArgs& a, hipStream_t s) {
   constexpr int QT = 32 * (4 / (GROUP * KSPLIT));
@@ -545,7 +554,7 @@ const char* launch_fattn_enc(const AttnArgs& a, hipStream_t s) {
   if (a.q_rs % 4 != 0 || a.kv_rs % 4 != 0 || a.o_rs % 4 != 0) return "fattn: row strides must be multiples of 4";
   if (a.q16) {  // bf16 q/k/v projections (k and v point into the same bf16 buffer)
     if (a.q_rs % 8 != 0 || a.kv_rs % 8 != 0) return "fattn: bf16 row strides must be multiples of 8";
-    if (fattn_dma_on()) launch_dma<64, 1, false>(a, s);
+    if (fattn_dma_ok(a)) launch_dma<64, 1, false>(a, s);
     else launch_f<64, 1, false, uint16_t>(a, s);
   } else {
     launch_f<64, 1, false, float>(a, s);
@@ -560,7 +569,7 @@ const char* launch_fattn_prefill(const AttnArgs& a, int group, hipStream_t s) {
   // key halves per workgroup when the plain shape leaves most CUs without a workgroup (one or a few clips); knob for A/B runs
   static const int ks_wgs = [] { const char* e = getenv("Q3A_FATTN_KSPLIT_MAX_WGS"); return e ? atoi(e) : 128; }();  // measured: 1 clip (56 workgroups) 22.6 -> 17.7 us per layer, 8 clips (448) 6.8 -> 7.4 ms prefill
   const long wgs64 = (long)((a.max_len + 63) / 64) * a.n_kv_heads * a.n_segs;
-  const bool dma = fattn_dma_on() && a.q16 && a.kv_rs % 8 == 0;
+  const bool dma = fattn_dma_ok(a);
   if (group == 1) { if (dma) launch_dma<128, 1, true>(a, s); else launch_f<128, 1, true, uint16_t>(a, s); }
   else if (group == 2 && wgs64 < ks_wgs) launch_f<128, 2, true, uint16_t, 2>(a, s);
   else if (group == 2) { if (dma) launch_dma<128, 2, true>(a, s); else launch_f<128, 2, true, uint16_t>(a, s); }

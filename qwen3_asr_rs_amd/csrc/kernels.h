@@ -63,7 +63,7 @@ struct Knobs {
   std::atomic<int> fuse_qkrope{1};              // Q3A_FUSE_QKROPE: QK-norm + RoPE + cache append as the qkv GEMM's epilogue
   std::atomic<int> skinny_q{1};                 // Q3A_SKINNY_Q: quarter workgroups for the o / down projections
   std::atomic<int> fuse_qkv_attn{0};            // Q3A_FUSE_QKV_ATTN: one-sequence decode qkv projection + attention in one launch
-  std::atomic<int> eos_run_ahead{1};            // Q3A_EOS_RUN_AHEAD: decode steps kept enqueued ahead of the device in natural-EOS mode (round 4: 1 -- no step past the last EOS; 2 costs the same and wastes one)
+  std::atomic<int> eos_run_ahead{1};            // Q3A_EOS_RUN_AHEAD: decode steps kept enqueued ahead of the device in natural-EOS mode (1: no whole-batch step runs past the last EOS.  Paired on one engine, tools/eos_probe.py: 1 and 2 both +0.91 ms on the fixed-N run with 100 / 101 steps executed; bench.py's natural_eos leg: +0.2 ms (r4 builder box), -0.05 ms (r4 driver box) against a fixed-N run of the same engine)
   std::atomic<int> gemm16_ring{1};              // Q3A_GEMM16_RING: 3-4-stage LDS rings with counted vmcnt in the small-M GEMMs (0: two stages, one barrier per K tile)
   std::atomic<int> rope_variant{0};             // Q3A_ROPE_VARIANT (experiment): arithmetic form of qknorm_rope_kv_kernel (dev.h head_norm_rope)
   std::atomic<int> rope_twice{0};               // Q3A_DEBUG_ROPE_TWICE (debug): re-execute the trailing rows' rope kernel into shadow buffers and compare

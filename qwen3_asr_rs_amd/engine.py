@@ -172,11 +172,34 @@ class HipEngine:
         self._chk(self._lib.q3a_fetch_ids(self._h, _i32p(out), stride, _i32p(lens)))
         return [out[b, :min(int(lens[b]), stride)].tolist() for b in range(self.batch)]
 
+    @staticmethod
+    def _ptrs(clips: Sequence[np.ndarray]):
+        """One pointer per utterance (q3a_transcribe_batch_ptrs): float32 C-contiguous arrays are passed as they are -- no
+        concatenation, no copy on the Python side.  Returns (kept-alive arrays, void* array, int64 lengths)."""
+        arrs = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        ns = np.array([a.size for a in arrs], dtype=np.int64)
+        return arrs, ptrs, ns
+
     def transcribe_batch(self, clips: Sequence[np.ndarray], lang_prefix_ids: Optional[Sequence[int]] = None,
                          max_new: int = 4096, fixed_new_tokens: int = 0) -> List[List[int]]:
-        self.upload_pcm(clips)
-        self.run_resident(lang_prefix_ids, max_new, fixed_new_tokens)
-        return self.fetch_ids(fixed_new_tokens if fixed_new_tokens > 0 else max_new)
+        """AsrInference::transcribe steps 2-8 for a batch, host PCM -> ids on the host, ONE call through the C ABI."""
+        arrs, ptrs, ns = self._ptrs(clips)
+        B = len(arrs)
+        stride = fixed_new_tokens if fixed_new_tokens > 0 else max_new
+        out = np.zeros((B, stride), dtype=np.int32)
+        lens = np.zeros(B, dtype=np.int32)
+        pre = np.asarray(lang_prefix_ids if lang_prefix_ids is not None else [], dtype=np.int32)
+        self._chk(self._lib.q3a_transcribe_batch_ptrs(self._h, ptrs, _i64p(ns), B, _i32p(pre) if len(pre) else None, len(pre), max_new,
+                                                      fixed_new_tokens, _i32p(out), stride, _i32p(lens)))
+        self.batch = B
+        return [out[b, :min(int(lens[b]), stride)].tolist() for b in range(B)]
+
+    def io_timings(self) -> dict:
+        """Input side of the last transcribe_batch (q3a_io_timings_last)."""
+        t = _lib.IoTimings()
+        self._chk(self._lib.q3a_io_timings_last(self._h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in _lib.IoTimings._fields_}
 
     # ---- measurement / debug --------------------------------------------------------------------------
     def timings(self) -> dict:
@@ -255,14 +278,14 @@ class HipGroup:
 
     def transcribe_batch(self, clips: Sequence[np.ndarray], lang_prefix_ids: Optional[Sequence[int]] = None,
                          max_new: int = 4096, fixed_new_tokens: int = 0) -> List[List[int]]:
-        pcm, ns = HipEngine._concat(clips)
-        B = len(clips)
+        arrs, ptrs, ns = HipEngine._ptrs(clips)
+        B = len(arrs)
         stride = fixed_new_tokens if fixed_new_tokens > 0 else max_new
         out = np.zeros((B, stride), dtype=np.int32)
         lens = np.zeros(B, dtype=np.int32)
         pre = np.asarray(lang_prefix_ids if lang_prefix_ids is not None else [], dtype=np.int32)
-        rc = self._lib.q3a_group_transcribe(self._h, _f32p(pcm), _i64p(ns), B, _i32p(pre) if len(pre) else None, len(pre), max_new,
-                                            fixed_new_tokens, _i32p(out), stride, _i32p(lens))
+        rc = self._lib.q3a_group_transcribe_ptrs(self._h, ptrs, _i64p(ns), B, _i32p(pre) if len(pre) else None, len(pre), max_new,
+                                                 fixed_new_tokens, _i32p(out), stride, _i32p(lens))
         if rc != 0:
             raise Q3aError((self._lib.q3a_group_last_error(self._h) or b"").decode())
         return [out[b, :min(int(lens[b]), stride)].tolist() for b in range(B)]

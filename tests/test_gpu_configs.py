@@ -25,7 +25,8 @@ from qwen3_asr_rs_amd.engine import HipEngine
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = 0.10          # default-mode max |logit error| at 0.6B / 1.7B dims: 1.7 % of |logit| <= ~6 (round 3: 0.05 at |logit| <= 3; measured 0.4-0.8 %)
+LOGIT_TOL = 0.06          # default-mode max |logit error| at 0.6B / 1.7B dims with |logit| <= ~6: 1 % of the logit scale (measured over rounds 4-5:
+                          # 0.022-0.046, i.e. 0.4-0.8 %; round 4 carried 0.10 = 2x slack, round 3: 0.05 at |logit| <= 3)
 EMBED_TOL = 2e-2          # rel-L2 of the audio embeddings
 MAX_UNDER_MARGIN = 0.10   # at most this fraction of the compared steps may sit inside the rounding noise (round 3: 0.20 with the
                           # flat logits of embedding scale 0.02, measured 7-14.5 %; expected ~0 with PEAKED_EMBED_SCALE)
@@ -66,7 +67,8 @@ def margin_report(tag, eng_tokens, eng_logits, ref, tol=None):
     print(f"[parity] {tag}: {n} steps, flips {flips}, under-margin {under} ({100.0 * under / n:.1f} %), worst |logit err| {worst:.4f}")
     assert worst <= (LOGIT_TOL if tol is None else tol), (tag, worst)
     assert under <= MAX_UNDER_MARGIN * n, f"{tag}: {under}/{n} steps under the margin -- the exact-id bound is vacuous"
-    assert flips <= max(1, MAX_FLIPS * n), f"{tag}: {flips}/{n} greedy ids differ from the oracle"
+    # (no `max(1, ...)`: under 20 steps not a single flip is allowed -- every flip has already passed the pair condition above)
+    assert flips <= MAX_FLIPS * n, f"{tag}: {flips}/{n} greedy ids differ from the oracle"
     return flips, under, worst
 
 

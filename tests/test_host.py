@@ -306,3 +306,46 @@ def test_bench_native_group_leg_is_a_bounded_child(monkeypatch):
     assert rec["value"] is None and "no result within 2 s" in rec["error"] and time.time() - t0 < 30, rec
     monkeypatch.setattr(bench.subprocess, "run", lambda cmd, **kw: real_run([sys.executable, "-c", "print('noise'); print('{\"workload\": \"q3a_group_transcribe\", \"value\": 7.0}')"], **kw))
     assert bench.native_group_child(args, 2, 1)["value"] == 7.0
+
+
+def _cpp_function_body(src: str, signature_start: str) -> str:
+    """Text of the brace-balanced body that follows `signature_start` in a C++ source."""
+    i = src.index(signature_start)
+    j = src.index("{", i)
+    depth, k = 0, j
+    while True:
+        c = src[k]
+        if c == "{":
+            depth += 1
+        elif c == "}":
+            depth -= 1
+            if depth == 0:
+                return src[j:k + 1]
+        k += 1
+
+
+def test_step_buffers_cover_the_captured_step():
+    """A cached decode-step graph holds raw device addresses.  Two guards keep a stale one from replaying -- the reallocation
+    sweep of setup_prompts and the address hash in make_graph_sig -- and both walk q3a_engine::step_bufs().  This test scans
+    the source of every function that enqueues a launch of the captured step for DevBuf members and fails when one is not
+    in that list ("one forgotten DevBuf re-opens the stale-graph bug")."""
+    src = open(os.path.join(ROOT, "qwen3_asr_rs_amd", "csrc", "engine.cpp")).read()
+    members = set()
+    for decl in re.findall(r"^  DevBuf ([^;]+);", src, flags=re.M):
+        members.update(n.strip() for n in decl.split(","))
+    assert {"kcache", "x_dec", "logits", "nn_ss"} <= members
+    listed = set(re.findall(r"&(\w+)", _cpp_function_body(src, "std::vector<DevBuf*> step_bufs()")))
+    assert listed <= members and len(listed) >= 20
+    step_functions = ["void decode_layer(", "void run_head(", "void enqueue_decode_step(", "void* kc_layer(", "void* vc_layer(",
+                      "NextNormOut first_layer_norm_out(", "uint16_t* nn_x_g(", "float* nn_ss_g(", "float* s_ctx_g(", "float* s_act_g(",
+                      "void batched_proj("]
+    used = set()
+    for f in step_functions:
+        body = _cpp_function_body(src, f)
+        used.update(m for m in members if re.search(r"\b" + re.escape(m) + r"\b", body))
+    debug_only = {n for n in used if n.startswith("dbg_")}
+    missing = used - listed - debug_only
+    assert not missing, f"DevBuf members used by the captured decode step but absent from step_bufs(): {sorted(missing)}"
+    # both guards really use the list
+    assert "step_bufs()" in _cpp_function_body(src, "std::string make_graph_sig() const")
+    assert "step_bufs()" in _cpp_function_body(src, "void setup_prompts(")
