@@ -282,6 +282,13 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *   "gemm256_resid_prefetch"  1 (default): the fp32-residual epilogue of the 256x256 GEMM (o / down / fc2 / out projections at
  *                        batch-sized row counts) requests the 16 residual rows of a 64-row pass before staging the pass; 0: the
  *                        loads sit inside the store loop, four dependent round trips per pass (A/B).  Same arithmetic either way.
+ *   "skinny_glu_2pass"   1 (default): a gate/up projection of the batched decode step that has more workgroups than the GPU has CUs
+ *                        (hidden 2048: 384) stages each wave's K slice in two passes and keeps the partial tile of the cross-wave
+ *                        reduction inside the wave's weight region, so that two workgroups fit on a CU; 0: one pass, one workgroup
+ *                        per CU, a full round and a half-empty one.  Same arithmetic.  Taken at the next prefill.
+ *   "fattn_pipe"         0 / 1: the MFMA flash attention of batch-sized encoder windows / prefills as the software-pipelined kernel
+ *                        (k_fattn.hip fattn_pipe_kernel: the softmax of key tile t issued between the QK MFMAs of tile t + 1, a ring
+ *                        of four LDS stages) instead of fattn_dma_kernel; bit-identical results.  Read at every launch.
  *   "rope_variant"       hazard-isolation builds only (-DQ3A_ROPE_EXPERIMENT, never the product library): arithmetic form of
  *                        qknorm_rope_kv_kernel (csrc/dev.h head_norm_rope; tools/soak_engines.py).  Ignored by the product library.
  *   "rope_twice"         debug, 0 (default) / 1: batch-sized prefills execute the trailing rows' rope kernel a second time into

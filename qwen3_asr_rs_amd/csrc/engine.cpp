@@ -115,6 +115,8 @@ Knobs& knobs() {
     env("Q3A_LIVE_KEY_SPLITS", k.live_key_splits);
     env("Q3A_GEMM16_RING", k.gemm16_ring);
     env("Q3A_GEMM256_RESID_PREFETCH", k.gemm256_resid_prefetch);
+    env("Q3A_FATTN_PIPE", k.fattn_pipe);
+    env("Q3A_SKINNY_GLU_2PASS", k.skinny_glu_2pass);
     env("Q3A_ROPE_VARIANT", k.rope_variant);
     env("Q3A_DEBUG_ROPE_TWICE", k.rope_twice);
   });
@@ -175,7 +177,7 @@ struct q3a_engine {
   int gsize = 32;  // sequences per group of the batched decode step (<= 32: one skinny-GEMM weight sweep), fixed per batch
   // knobs that shape the decode step, latched per batch in setup_prompts: producers outside the captured graph (prefill
   // finalize, set_tokens) and the captured step must agree on them, and the graph signature names them
-  int k_parallel_groups = 1, k_skinny_q = 1, k_fuse_qkv_attn = 0, k_dattn_batched_min_wgs = 128;
+  int k_parallel_groups = 1, k_skinny_q = 1, k_fuse_qkv_attn = 0, k_dattn_batched_min_wgs = 128, k_skinny_glu_2pass = 1;
   std::vector<hipStream_t> chain_streams;
   std::vector<hipEvent_t> join_ev;
   hipEvent_t fork_ev = nullptr;
@@ -638,8 +640,11 @@ struct q3a_engine {
 
   // =====================================================================================
   // prompts: ids concatenated, lens[B]  (inference.rs:104-137)
-  void setup_prompts(const int32_t* ids_h, const int32_t* lens, int b, int max_new_req) {
-    if (!have_enc) fail("q3a_prefill: no encoder output (call q3a_encode first)");
+  // before_encoder: the whole-path entry points build the prompts BEFORE they enqueue anything of the batch -- the tables only
+  // depend on T[] (host integers of set_batch), and the stream synchronisation below then meets an idle stream instead of
+  // draining the encoder between its last kernel and the prefill's first
+  void setup_prompts(const int32_t* ids_h, const int32_t* lens, int b, int max_new_req, bool before_encoder = false) {
+    if (!have_enc && !before_encoder) fail("q3a_prefill: no encoder output (call q3a_encode first)");
     if (b != B) fail("q3a_prefill: batch size differs from the encoded batch");
     P.assign(lens, lens + b);
     seq_off.resize(b);
@@ -702,6 +707,7 @@ struct q3a_engine {
       gsize = (gs >= 1 && gs <= 32) ? gs : 32;
       k_parallel_groups = kn.decode_parallel_groups.load(); k_skinny_q = kn.skinny_q.load();
       k_fuse_qkv_attn = kn.fuse_qkv_attn.load(); k_dattn_batched_min_wgs = kn.dattn_batched_min_wgs.load();
+      k_skinny_glu_2pass = kn.skinny_glu_2pass.load();
     }
     const size_t ng = (size_t)n_groups(b);  // groups of <= gsize sequences of the batched decode step
     if (!xcd_sync.p) { xcd_sync.ensure(2 * 8 * 64 * 4); HIPCHK(hipMemset(xcd_sync.p, 0, 2 * 8 * 64 * 4)); }  // (never inside a capture)
@@ -1035,6 +1041,7 @@ struct q3a_engine {
     if (pre) { u.xw16f = nn_x_g(grp); u.ss_parts = nn_ss_g(grp); u.ss_nparts = nn_parts(); }
     else u.rms_w = wf(l.post_ln);
     u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act_g(grp); u.out16 = b16 ? reinterpret_cast<uint16_t*>(s_act_g(grp)) : nullptr; u.out16_frag = b16; u.ldo = I;
+    u.glu_1pass = k_skinny_glu_2pass == 0;
     timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_skinny(u, precise(), ks)); });
     SkinnyArgs dn{};
     dn.fast_math = precise() ? 0 : 1;
@@ -1092,8 +1099,8 @@ struct q3a_engine {
       for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; }
     }
     char buf[256];
-    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d.%d/%d/%d/%p/%016llx", B, gsize, k_parallel_groups, k_skinny_q, k_fuse_qkv_attn,
-             k_dattn_batched_min_wgs, (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
+    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d.%d.%d/%d/%d/%p/%016llx", B, gsize, k_parallel_groups, k_skinny_q, k_fuse_qkv_attn,
+             k_dattn_batched_min_wgs, k_skinny_glu_2pass, (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
     return buf;
   }
 
@@ -1166,18 +1173,12 @@ struct q3a_engine {
   }
 
   // steps 2-8 on the resident batch
-  // mel_enqueued: upload_ptrs_and_mel() has put the (upload-overlapped) log-mel on the stream and recorded ev[0] / ev[1]
-  void run_resident(const int32_t* lang_ids, int n_prefix, int max_new_req, int fixed_new, bool mel_enqueued = false) {
+  // prompts of the resident batch (inference.rs:104-137, 215-257) and every table / buffer of the prefill + decode: host integers
+  // only (T[] of set_batch), so this runs before the batch's first kernel is enqueued
+  void prepare_prompts(const int32_t* lang_ids, int n_prefix, int max_new_req, int fixed_new) {
     if (B <= 0) fail("q3a_run_resident: no batch uploaded");
     if (fixed_new > 0) max_new_req = fixed_new;
     if (max_new_req <= 0) max_new_req = opts.max_new_tokens;
-    if (!mel_enqueued) {
-      HIPCHK(hipEventRecord(ev[0], stream));
-      run_mel();
-      HIPCHK(hipEventRecord(ev[1], stream));
-    }
-    run_encoder();
-    HIPCHK(hipEventRecord(ev[2], stream));
     std::vector<int32_t> ids_v, lens(B);
     for (int s = 0; s < B; ++s) {
       int32_t len = 0;
@@ -1187,7 +1188,20 @@ struct q3a_engine {
       q3a_build_prompt(T[s], lang_ids, n_prefix, ids_v.data() + o, &len);
       lens[s] = len;
     }
-    setup_prompts(ids_v.data(), lens.data(), B, max_new_req);
+    setup_prompts(ids_v.data(), lens.data(), B, max_new_req, true);
+  }
+
+  // mel_enqueued: upload_ptrs_and_mel() has put the (upload-overlapped) log-mel on the stream and recorded ev[0] / ev[1].
+  // The caller has run prepare_prompts() for this batch.
+  void run_resident(int fixed_new, bool mel_enqueued = false) {
+    if (B <= 0) fail("q3a_run_resident: no batch uploaded");
+    if (!mel_enqueued) {
+      HIPCHK(hipEventRecord(ev[0], stream));
+      run_mel();
+      HIPCHK(hipEventRecord(ev[1], stream));
+    }
+    run_encoder();
+    HIPCHK(hipEventRecord(ev[2], stream));
     run_prefill();
     HIPCHK(hipEventRecord(ev[3], stream));
     // the prefill already produced token 0; every decode step feeds one token and yields the next
@@ -1537,7 +1551,9 @@ int32_t q3a_run_resident(q3a_engine* e, const int32_t* lang_prefix_ids, int32_t 
   HIPCHK(hipSetDevice(e->device));
   e->fixed_mode_ = fixed_new_tokens > 0;
   e->head_logits_ = e->opts.debug_taps != 0;
-  e->run_resident(lang_prefix_ids, n_prefix, max_new, fixed_new_tokens);
+  e->have_mel = e->have_enc = e->have_prefill = false;
+  e->prepare_prompts(lang_prefix_ids, n_prefix, max_new, fixed_new_tokens);
+  e->run_resident(fixed_new_tokens);
   Q3A_CATCH(e)
 }
 
@@ -1559,10 +1575,12 @@ int32_t q3a_transcribe_batch_ptrs(q3a_engine* e, const float* const* pcm16k, con
     if (!pcm16k[u]) fail("q3a_transcribe_batch: null utterance pointer");
   const auto w0 = std::chrono::steady_clock::now();
   HIPCHK(hipSetDevice(e->device));
-  e->upload_ptrs_and_mel(pcm16k, n_samples, B);
   e->fixed_mode_ = fixed_new_tokens > 0;
   e->head_logits_ = e->opts.debug_taps != 0;
-  e->run_resident(lang_prefix_ids, n_prefix, max_new, fixed_new_tokens, true);
+  e->set_batch(n_samples, B);  // geometry first: the prompts only need the lengths, and their set-up synchronises an idle stream
+  e->prepare_prompts(lang_prefix_ids, n_prefix, max_new, fixed_new_tokens);
+  e->upload_ptrs_and_mel(pcm16k, n_samples, B);
+  e->run_resident(fixed_new_tokens, true);
   e->fetch_ids(out_ids, stride, out_lens);
   if (e->io.mode != 0) {
     float ms = 0.f;
@@ -1731,6 +1749,8 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (strcmp(key, "live_key_splits") == 0) { kn.live_key_splits = value; return 0; }
   if (strcmp(key, "gemm16_ring") == 0) { kn.gemm16_ring = value; return 0; }
   if (strcmp(key, "gemm256_resid_prefetch") == 0) { kn.gemm256_resid_prefetch = value; return 0; }
+  if (strcmp(key, "fattn_pipe") == 0) { kn.fattn_pipe = value; return 0; }
+  if (strcmp(key, "skinny_glu_2pass") == 0) { kn.skinny_glu_2pass = value; return 0; }
   if (strcmp(key, "rope_variant") == 0) { kn.rope_variant = value; return 0; }
   if (strcmp(key, "rope_twice") == 0) { kn.rope_twice = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";

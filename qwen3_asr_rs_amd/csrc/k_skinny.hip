@@ -66,14 +66,26 @@ __device__ __forceinline__ float sq4(const float4& a) { return a.x * a.x + a.y *
 // activation matrix through one CU's L1 (the measured bound of these kernels) while 192 CUs idle; 256 quarter workgroups
 // move half the bytes each.  The two halves of a row tile sit 8 apart in dispatch order (same XCD): the second weight
 // read is an L2 hit, so the weight stream uses the default cache policy here instead of nt.
-template <bool SPLIT, int TILES, int SH, int XMODE, int UNR, bool WLDS, bool QS = false>
+// PALIAS (round 5): the wave's partial tile of the cross-wave reduction lives in the wave's OWN weight region of the dynamic LDS (the
+// wave has consumed its weights when it stores its partials; LDS operations of a wave are in order) instead of a static array.
+// That takes 17-35 KB off the workgroup's LDS footprint: a 2-tile (gate + up) workgroup whose K slice is staged in two passes then
+// needs 64.5 KiB, so TWO of them fit on a CU.  The gate/up projection at hidden 2048 has 384 workgroups: with one resident per CU
+// it ran as a full round and a half-empty one (14.8 us for 50 MB at 16 sequences, profiles/r5_kernel_trace_1p7b_b16.txt).
+template <bool SPLIT, int TILES, int SH, int XMODE, int UNR, bool WLDS, bool QS = false, bool PALIAS = false>
 __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   static_assert(!(SPLIT && XMODE >= 2), "the precise mode keeps fp32 activations");
   static_assert(!WLDS || UNR % 2 == 0, "the LDS image is made of 64-wide k columns");
   static_assert(!QS || (TILES == 1 && SH == 1 && XMODE == 2 && WLDS), "quarter workgroups: bf16 fragment-order x, LDS-staged weights");
   constexpr int PIECES = QS ? 1 : 2;  // 8-row x 128-B DMA pieces per (tile, 64-wide k column)
+  constexpr int WREGION = TILES * (UNR / 2) * PIECES * 1024;  // bytes of a wave's weight region
+  constexpr int PART_W = TILES * SH * 16 * 17;                // floats of a wave's partial tile
+  static_assert(!PALIAS || (WLDS && PART_W * 4 <= WREGION), "the partial tile must fit the wave's weight region");
   extern __shared__ __attribute__((aligned(16))) unsigned char wlds[];  // WLDS: [wave][tile][UNR/2 columns][16 rows][128 B]
-  __shared__ float part[SK_WAVES][TILES][SH][16][17];  // [k-slice][tile][seq half][row][sequence] (+1 pad)
+  __shared__ float part_static[PALIAS ? 1 : SK_WAVES * PART_W];  // [k-slice][tile][seq half][row][sequence] (+1 pad)
+  auto part = [&](int w, int t, int h, int row, int col) -> float& {
+    float* base = PALIAS ? reinterpret_cast<float*>(wlds + (size_t)w * WREGION) : part_static + w * PART_W;
+    return base[((t * SH + h) * 16 + row) * 17 + col];
+  };
   __shared__ float ssp[SK_WAVES][SH][16];              // XMODE 1: sum(x^2) of each sequence over the wave's K slice
   // every argument this instantiation touches, in one scalar-load clause (dev.h Q3A_ARG)
   Q3A_ARG(a.W); Q3A_ARG(a.N); Q3A_ARG(a.K); Q3A_ARG(a.S); Q3A_ARG(a.ldx); Q3A_ARG(a.bias); Q3A_ARG(a.mode); Q3A_ARG(a.out); Q3A_ARG(a.ldo);
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
         ssq[h][j] = p < a.ss_nparts ? v : 0.f;
       }
   }
-  unsigned char* const wbase = wlds + (size_t)wave * (TILES * (UNR / 2) * PIECES * 1024);
+  unsigned char* const wbase = wlds + (size_t)wave * WREGION;
   for (int kb = ks0; kb < ks1; kb += UNR) {
     uint4 wv[WLDS ? 1 : UNR][TILES];
     float4 x0[UNR][SH], x1[UNR][SH], w0[UNR], w1[UNR];
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
 #pragma unroll
     for (int h = 0; h < SH; ++h)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) part[wave][t][h][kc * 4 + r][l15] = acc[t][h][r];
+      for (int r = 0; r < 4; ++r) part(wave, t, h, kc * 4 + r, l15) = acc[t][h][r];
   if (XMODE == 3) {  // sum(x^2) comes from the producer's partials (requested before the K loop, see there)
 #pragma unroll
     for (int h = 0; h < SH; ++h) {
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   for (int t = 0; t < TILES; ++t) {
     v[t] = 0.f;
 #pragma unroll
-    for (int w = 0; w < SK_WAVES; ++w) v[t] += part[w][t][sh][i][sj];
+    for (int w = 0; w < SK_WAVES; ++w) v[t] += part(w, t, sh, i, sj);
   }
   if (XMODE == 1 || XMODE == 3) {
     float q = 0.f;
@@ -341,6 +353,17 @@ void launch_k(const SkinnyArgs& a, dim3 grid, hipStream_t s) {
   const int steps = a.K / 32, per = (steps + SK_WAVES - 1) / SK_WAVES;
   const size_t wbytes = (size_t)SK_WAVES * TILES * (UNR / 2) * 2048;
   static const bool wlds_on = [] { const char* e = getenv("Q3A_SKINNY_WLDS"); return !e || atoi(e) != 0; }();  // A/B knob
+  if constexpr (TILES == 2 && UNR % 4 == 0 && UNR >= 8 && !SPLIT && XMODE >= 2) {
+    // more workgroups than CUs (gate/up at hidden 2048: 384): two passes of UNR / 2 steps with the partial tile aliased into the
+    // weight region -> 64.5 KiB per workgroup, two resident per CU, no half-empty second round (A/B knob skinny_glu_2pass = 0 -> SkinnyArgs::glu_1pass)
+    const bool two_pass = a.glu_1pass == 0;
+    static const int n_cu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    if (wlds_on && two_pass && (int)grid.x > n_cu && per == UNR && steps % per == 0) {
+      const size_t wb2 = (size_t)SK_WAVES * TILES * (UNR / 4) * 2048;
+      hipLaunchKernelGGL((skinny_kernel<SPLIT, TILES, SH, XMODE, UNR / 2, true, false, true>), grid, block, wb2, s, a);
+      return;
+    }
+  }
   if constexpr (UNR % 2 == 0 && !SPLIT) {
     // (K = 6144 at 1.7B: 24 steps per wave = two passes of 12; before, such shapes fell back to direct fragment loads:
     // down projection 14.8 us for 25 MB)
@@ -387,6 +410,11 @@ hipError_t allow_big_lds() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_kernel<false, TILES, SH, XMODE, UNR, true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sk_dyn_lds_max(TILES, SH));
 }
+template <int SH, int XMODE, int UNR>
+hipError_t allow_glu_2pass() {  // the two-pass gate/up form: UNR = steps per pass
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_kernel<false, 2, SH, XMODE, UNR, true, false, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, SK_WAVES * 2 * (UNR / 2) * 2048);
+}
 template <int XMODE, int UNR>
 hipError_t allow_big_lds_shapes() {
   hipError_t e = allow_big_lds<1, 1, XMODE, UNR>();
@@ -412,6 +440,14 @@ const char* skinny_init() {
   if (e == hipSuccess) e = allow_big_lds_shapes<0, 6>();
   if (e == hipSuccess) e = allow_big_lds_shapes<1, 4>();
   if (e == hipSuccess) e = allow_big_lds_shapes<1, 6>();
+  if (e == hipSuccess) e = allow_glu_2pass<1, 2, 4>();
+  if (e == hipSuccess) e = allow_glu_2pass<2, 2, 4>();
+  if (e == hipSuccess) e = allow_glu_2pass<1, 3, 4>();
+  if (e == hipSuccess) e = allow_glu_2pass<2, 3, 4>();
+  if (e == hipSuccess) e = allow_glu_2pass<1, 2, 6>();
+  if (e == hipSuccess) e = allow_glu_2pass<2, 2, 6>();
+  if (e == hipSuccess) e = allow_glu_2pass<1, 3, 6>();
+  if (e == hipSuccess) e = allow_glu_2pass<2, 3, 6>();
   return e == hipSuccess ? nullptr : "skinny gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
 }
 

@@ -65,6 +65,8 @@ struct Knobs {
   std::atomic<int> fuse_qkv_attn{0};            // Q3A_FUSE_QKV_ATTN: one-sequence decode qkv projection + attention in one launch
   std::atomic<int> eos_run_ahead{1};            // Q3A_EOS_RUN_AHEAD: decode steps kept enqueued ahead of the device in natural-EOS mode (1: no whole-batch step runs past the last EOS.  Paired on one engine, tools/eos_probe.py: 1 and 2 both +0.91 ms on the fixed-N run with 100 / 101 steps executed; bench.py's natural_eos leg: +0.2 ms (r4 builder box), -0.05 ms (r4 driver box) against a fixed-N run of the same engine)
   std::atomic<int> gemm16_ring{1};              // Q3A_GEMM16_RING: 3-4-stage LDS rings with counted vmcnt in the small-M GEMMs (0: two stages, one barrier per K tile)
+  std::atomic<int> skinny_glu_2pass{1};         // Q3A_SKINNY_GLU_2PASS: gate/up skinny GEMM with more workgroups than CUs stages its K slice in two passes, partial tile aliased into the weight region: two workgroups per CU (k_skinny.hip PALIAS)
+  std::atomic<int> fattn_pipe{0};               // Q3A_FATTN_PIPE: software-pipelined flash attention (k_fattn.hip fattn_pipe_kernel) instead of fattn_dma_kernel
   std::atomic<int> rope_variant{0};             // Q3A_ROPE_VARIANT (experiment): arithmetic form of qknorm_rope_kv_kernel (dev.h head_norm_rope)
   std::atomic<int> rope_twice{0};               // Q3A_DEBUG_ROPE_TWICE (debug): re-execute the trailing rows' rope kernel into shadow buffers and compare
   std::atomic<int> gemm256_resid_prefetch{1};   // Q3A_GEMM256_RESID_PREFETCH: fp32-residual epilogue of gemm256 requests a pass's 16 residual rows ahead of staging it (0: four dependent round trips inside the store loop)
@@ -218,6 +220,7 @@ struct SkinnyArgs {
   // N / 8 partial rows instead of N / 16 -- the caller sizes its buffers and the consumer's ss_nparts accordingly
   int qsplit;
   int qs_halves;  // (set by the launcher: 16-sequence halves per row tile)
+  int glu_1pass;  // 1: keep the gate/up projection's single-pass form even when it has more workgroups than CUs (A/B; knob skinny_glu_2pass = 0)
   int fast_math;  // default mode: hardware rsq / exp / rcp in the RMSNorm scale and SiLU of the epilogue (dev.h rstd_of)
   Q3A_STAMP_FIELD
 };

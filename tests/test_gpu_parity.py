@@ -316,6 +316,36 @@ def test_mfma_attention_matches_valu_attention(tiny_dir):
         assert rel_l2(a, b) <= 1e-2
 
 
+def test_pipelined_flash_attention_is_bit_identical(tiny_dir):
+    """k_fattn.hip fattn_pipe_kernel (knob fattn_pipe: the softmax of key tile t issued between the QK MFMAs of tile t + 1, ring
+    of four LDS stages) against fattn_dma_kernel: the same arithmetic in the same order per query, so encoder output, first
+    decoder layer and last-row logits must agree BIT FOR BIT.  Tiny dims with 24 ragged clips (enough workgroups for the DMA
+    kernels: head dim 64 with 1-5 key tiles per window and ragged tails; head dim 128, GQA 2, causal) and the 0.6B dimensions with
+    a ragged batch of 8 (windows of 104 tokens, prefills of 100-405 rows)."""
+    from qwen3_asr_rs_amd import _lib
+    lib = _lib.load()
+    d06 = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
+    cases = [(tiny_dir, [synthetic.synthetic_clip(100 + i, 0.7 + 0.61 * i) for i in range(24)]),
+             (d06, [synthetic.synthetic_clip(130 + i, [30.0, 7.3, 22.1, 30.0, 11.9, 3.4, 28.7, 16.0][i]) for i in range(8)])]
+    try:
+        for model_dir, clips in cases:
+            outs = []
+            for pipe in (0, 1):
+                assert lib.q3a_debug_set(b"fattn_pipe", pipe) == 0
+                eng = HipEngine(model_dir, 0, debug_taps=True, max_new_tokens=8)
+                eng.mel(clips)
+                emb = np.concatenate([e.ravel() for e in eng.encode()])
+                prompts = [HipEngine.build_prompt(eng.num_audio_tokens(len(c))) for c in clips]
+                logits, nxt = eng.prefill(prompts)
+                outs.append((emb, eng.debug_read("dec_layer0"), eng.debug_read("dec_last_hidden"), logits.ravel(), nxt))
+                eng.close()
+            for a, b in zip(outs[0], outs[1]):
+                assert np.isfinite(np.asarray(a, np.float64)).all()
+                assert np.array_equal(a, b), float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+    finally:
+        lib.q3a_debug_set(b"fattn_pipe", 0)
+
+
 def test_graph_replay_equals_eager(tiny_dir):
     clip = synthetic.synthetic_clip(4, 3.0)
     out = []
