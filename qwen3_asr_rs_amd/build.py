@@ -91,8 +91,13 @@ def isa_path(src: str) -> str:
 def scan_isa(paths=None):
     """Packed fp32 instructions with an op_sel bit set (low result half reading a HIGH source register), per kernel.
 
-    That form returned wrong low halves in lanes 48-63 on gfx950 while a second queue kept the GPU busy (csrc/dev.h,
-    profiles/r4_pk_op_sel_hazard.txt).  Returns [(file, kernel, instruction line)]; build() refuses a library that has any."""
+    Round 5's standalone sweep (tools/pk_hazard.hip -> profiles/r5_pk_hazard.txt) pins the failing set: v_pk_{mul,add,fma}_f32 whose
+    op_sel takes source 0 LOW and source 1 HIGH ([0,1], [0,1,0], [0,1,1]; any op_sel_hi) return the low half as if source 1 were 0 in
+    lanes 48-63 whenever a 16-bit-input MFMA (16x16x32 bf16 / f16, 32x32x16 bf16) is in flight on the same CU -- from another queue
+    or from other waves of the same kernel.  op_sel_hi-only forms (the only ones the library contains), the other op_sel patterns,
+    v_pk_mov_b32, packed f16, DPP and permlane forms never failed.  The scan flags ANY op_sel bit on the three packed-fp32
+    arithmetic instructions gfx950 has: a superset of the failing set.
+    Returns [(file, kernel, instruction line)]; build() refuses a library that has any."""
     if paths is None:
         paths = [isa_path(s) for s in SOURCES if s.endswith(".hip")]
     found = []

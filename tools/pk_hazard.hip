@@ -584,6 +584,9 @@ int main(int argc, char** argv) {
   for (auto& n : notes) printf("%s\n", n.c_str());
   printf("\n## forms\n");
   for (int f = 0; f < kNumForms; ++f) {
+    double ran = 0;
+    for (int ag = 0; ag < A_COUNT; ++ag) ran += execs[f][ag];
+    if (ran == 0) continue;  // not part of this run (--forms)
     unsigned long long tot = 0, ctl = table[f][A_NONE];
     for (int ag = 1; ag < A_COUNT; ++ag) tot += table[f][ag];
     printf("%-22s %-60s %s%s\n", kForms[f].name, kForms[f].text,
