@@ -34,6 +34,8 @@ extern "C" {
     pub fn q3a_last_error(e: *const q3a_engine) -> *const c_char;
     pub fn q3a_transcribe_batch(e: *mut q3a_engine, pcm16k: *const f32, n_samples: *const i64, b: i32, lang_prefix_ids: *const i32,
                                 n_prefix: i32, max_new: i32, fixed_new_tokens: i32, out_ids: *mut i32, stride: i32, out_lens: *mut i32) -> i32;
+    pub fn q3a_transcribe_batch_ptrs(e: *mut q3a_engine, pcm16k: *const *const f32, n_samples: *const i64, b: i32, lang_prefix_ids: *const i32,
+                                     n_prefix: i32, max_new: i32, fixed_new_tokens: i32, out_ids: *mut i32, stride: i32, out_lens: *mut i32) -> i32;
     pub fn q3a_group_create(model_dir: *const c_char, n_gpus: i32, devices: *const i32, opts: *const q3a_opts, out: *mut *mut q3a_group) -> i32;
     pub fn q3a_group_destroy(g: *mut q3a_group);
     pub fn q3a_group_size(g: *const q3a_group) -> i32;
@@ -41,6 +43,8 @@ extern "C" {
     pub fn q3a_group_startup_seconds(g: *const q3a_group, out4: *mut f64) -> i32;
     pub fn q3a_group_transcribe(g: *mut q3a_group, pcm16k: *const f32, n_samples: *const i64, b: i32, lang_prefix_ids: *const i32,
                                 n_prefix: i32, max_new: i32, fixed_new_tokens: i32, out_ids: *mut i32, stride: i32, out_lens: *mut i32) -> i32;
+    pub fn q3a_group_transcribe_ptrs(g: *mut q3a_group, pcm16k: *const *const f32, n_samples: *const i64, b: i32, lang_prefix_ids: *const i32,
+                                     n_prefix: i32, max_new: i32, fixed_new_tokens: i32, out_ids: *mut i32, stride: i32, out_lens: *mut i32) -> i32;
 }
 
 /// src/main.rs:51-65 for the `hip` feature: HIP devices visible to this process (0: none -- there is no CPU path).
@@ -72,13 +76,15 @@ impl HipEngine {
     pub fn transcribe_batch(&self, clips: &[&[f32]], lang_prefix_ids: &[i32], max_new: usize) -> Result<Vec<Vec<i64>>> {
         let b = clips.len();
         let n: Vec<i64> = clips.iter().map(|c| c.len() as i64).collect();
-        let pcm: Vec<f32> = clips.iter().flat_map(|c| c.iter().copied()).collect();
+        // one pointer per utterance: the Vec<f32> that load_audio (src/audio.rs:7) returned for each file is handed over as it is --
+        // no concatenation on the host; the library stages the pageable buffers into pinned memory and overlaps the copy with the mel
+        let ptrs: Vec<*const f32> = clips.iter().map(|c| c.as_ptr()).collect();
         let mut ids = vec![0i32; b * max_new];
         let mut lens = vec![0i32; b];
         let pre = if lang_prefix_ids.is_empty() { std::ptr::null() } else { lang_prefix_ids.as_ptr() };
         let rc = unsafe {
-            q3a_transcribe_batch(self.raw, pcm.as_ptr(), n.as_ptr(), b as i32, pre, lang_prefix_ids.len() as i32, max_new as i32, 0,
-                                 ids.as_mut_ptr(), max_new as i32, lens.as_mut_ptr())
+            q3a_transcribe_batch_ptrs(self.raw, ptrs.as_ptr(), n.as_ptr(), b as i32, pre, lang_prefix_ids.len() as i32, max_new as i32, 0,
+                                      ids.as_mut_ptr(), max_new as i32, lens.as_mut_ptr())
         };
         if rc != 0 { bail!("{}", msg(unsafe { q3a_last_error(self.raw) })); }
         Ok((0..b).map(|i| ids[i * max_new..i * max_new + lens[i] as usize].iter().map(|&x| x as i64).collect()).collect())
@@ -112,13 +118,13 @@ impl HipGroup {
     pub fn transcribe_batch(&self, clips: &[&[f32]], lang_prefix_ids: &[i32], max_new: usize) -> Result<Vec<Vec<i64>>> {
         let b = clips.len();
         let n: Vec<i64> = clips.iter().map(|c| c.len() as i64).collect();
-        let pcm: Vec<f32> = clips.iter().flat_map(|c| c.iter().copied()).collect();
+        let ptrs: Vec<*const f32> = clips.iter().map(|c| c.as_ptr()).collect();
         let mut ids = vec![0i32; b * max_new];
         let mut lens = vec![0i32; b];
         let pre = if lang_prefix_ids.is_empty() { std::ptr::null() } else { lang_prefix_ids.as_ptr() };
         let rc = unsafe {
-            q3a_group_transcribe(self.raw, pcm.as_ptr(), n.as_ptr(), b as i32, pre, lang_prefix_ids.len() as i32, max_new as i32, 0,
-                                 ids.as_mut_ptr(), max_new as i32, lens.as_mut_ptr())
+            q3a_group_transcribe_ptrs(self.raw, ptrs.as_ptr(), n.as_ptr(), b as i32, pre, lang_prefix_ids.len() as i32, max_new as i32, 0,
+                                      ids.as_mut_ptr(), max_new as i32, lens.as_mut_ptr())
         };
         if rc != 0 { bail!("{}", msg(unsafe { q3a_group_last_error(self.raw) })); }
         Ok((0..b).map(|i| ids[i * max_new..i * max_new + lens[i] as usize].iter().map(|&x| x as i64).collect()).collect())
