@@ -286,6 +286,11 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *                        (hidden 2048: 384) stages each wave's K slice in two passes and keeps the partial tile of the cross-wave
  *                        reduction inside the wave's weight region, so that two workgroups fit on a CU; 0: one pass, one workgroup
  *                        per CU, a full round and a half-empty one.  Same arithmetic.  Taken at the next prefill.
+ *   "skinny_glu_hp3"     1 (default): when the gate/up projection of the batched decode step has more 32-row pair tiles than the GPU has
+ *                        CUs and its output columns divide into 3 half-pair tiles (8 gate + 8 up rows in one MFMA fragment) per
+ *                        workgroup with at most one workgroup per CU (hidden 2048 / inter 6144: 256 workgroups), it runs in that
+ *                        form: every CU streams the same number of weight bytes and the activations once; 0: never; 2: whenever
+ *                        the shape allows (tests).  Same arithmetic.  Taken at the next prefill.
  *   "fattn_pipe"         0 / 1: the MFMA flash attention of batch-sized encoder windows / prefills as the software-pipelined kernel
  *                        (k_fattn.hip fattn_pipe_kernel: the softmax of key tile t issued between the QK MFMAs of tile t + 1, a ring
  *                        of four LDS stages) instead of fattn_dma_kernel; bit-identical results.  Read at every launch.

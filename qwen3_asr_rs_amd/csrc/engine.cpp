@@ -117,6 +117,7 @@ Knobs& knobs() {
     env("Q3A_GEMM256_RESID_PREFETCH", k.gemm256_resid_prefetch);
     env("Q3A_FATTN_PIPE", k.fattn_pipe);
     env("Q3A_SKINNY_GLU_2PASS", k.skinny_glu_2pass);
+    env("Q3A_SKINNY_GLU_HP3", k.skinny_glu_hp3);
     env("Q3A_ROPE_VARIANT", k.rope_variant);
     env("Q3A_DEBUG_ROPE_TWICE", k.rope_twice);
   });
@@ -177,7 +178,7 @@ struct q3a_engine {
   int gsize = 32;  // sequences per group of the batched decode step (<= 32: one skinny-GEMM weight sweep), fixed per batch
   // knobs that shape the decode step, latched per batch in setup_prompts: producers outside the captured graph (prefill
   // finalize, set_tokens) and the captured step must agree on them, and the graph signature names them
-  int k_parallel_groups = 1, k_skinny_q = 1, k_fuse_qkv_attn = 0, k_dattn_batched_min_wgs = 128, k_skinny_glu_2pass = 1;
+  int k_parallel_groups = 1, k_skinny_q = 1, k_fuse_qkv_attn = 0, k_dattn_batched_min_wgs = 128, k_skinny_glu_2pass = 1, k_skinny_glu_hp3 = 1;
   std::vector<hipStream_t> chain_streams;
   std::vector<hipEvent_t> join_ev;
   hipEvent_t fork_ev = nullptr;
@@ -708,6 +709,7 @@ struct q3a_engine {
       k_parallel_groups = kn.decode_parallel_groups.load(); k_skinny_q = kn.skinny_q.load();
       k_fuse_qkv_attn = kn.fuse_qkv_attn.load(); k_dattn_batched_min_wgs = kn.dattn_batched_min_wgs.load();
       k_skinny_glu_2pass = kn.skinny_glu_2pass.load();
+      k_skinny_glu_hp3 = kn.skinny_glu_hp3.load();
     }
     const size_t ng = (size_t)n_groups(b);  // groups of <= gsize sequences of the batched decode step
     if (!xcd_sync.p) { xcd_sync.ensure(2 * 8 * 64 * 4); HIPCHK(hipMemset(xcd_sync.p, 0, 2 * 8 * 64 * 4)); }  // (never inside a capture)
@@ -1042,6 +1044,7 @@ struct q3a_engine {
     else u.rms_w = wf(l.post_ln);
     u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act_g(grp); u.out16 = b16 ? reinterpret_cast<uint16_t*>(s_act_g(grp)) : nullptr; u.out16_frag = b16; u.ldo = I;
     u.glu_1pass = k_skinny_glu_2pass == 0;
+    u.glu_hp3 = k_skinny_glu_hp3;
     timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_skinny(u, precise(), ks)); });
     SkinnyArgs dn{};
     dn.fast_math = precise() ? 0 : 1;
@@ -1099,8 +1102,8 @@ struct q3a_engine {
       for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; }
     }
     char buf[256];
-    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d.%d.%d/%d/%d/%p/%016llx", B, gsize, k_parallel_groups, k_skinny_q, k_fuse_qkv_attn,
-             k_dattn_batched_min_wgs, k_skinny_glu_2pass, (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
+    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d.%d.%d.%d/%d/%d/%p/%016llx", B, gsize, k_parallel_groups, k_skinny_q, k_fuse_qkv_attn,
+             k_dattn_batched_min_wgs, k_skinny_glu_2pass, k_skinny_glu_hp3, (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
     return buf;
   }
 
@@ -1751,6 +1754,7 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (strcmp(key, "gemm256_resid_prefetch") == 0) { kn.gemm256_resid_prefetch = value; return 0; }
   if (strcmp(key, "fattn_pipe") == 0) { kn.fattn_pipe = value; return 0; }
   if (strcmp(key, "skinny_glu_2pass") == 0) { kn.skinny_glu_2pass = value; return 0; }
+  if (strcmp(key, "skinny_glu_hp3") == 0) { kn.skinny_glu_hp3 = value; return 0; }
   if (strcmp(key, "rope_variant") == 0) { kn.rope_variant = value; return 0; }
   if (strcmp(key, "rope_twice") == 0) { kn.rope_twice = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";

@@ -71,9 +71,16 @@ __device__ __forceinline__ float sq4(const float4& a) { return a.x * a.x + a.y *
 // That takes 17-35 KB off the workgroup's LDS footprint: a 2-tile (gate + up) workgroup whose K slice is staged in two passes then
 // needs 64.5 KiB, so TWO of them fit on a CU.  The gate/up projection at hidden 2048 has 384 workgroups: with one resident per CU
 // it ran as a full round and a half-empty one (14.8 us for 50 MB at 16 sequences, profiles/r5_kernel_trace_1p7b_b16.txt).
-template <bool SPLIT, int TILES, int SH, int XMODE, int UNR, bool WLDS, bool QS = false, bool PALIAS = false>
+// HP ("half pair" gate/up tiles, round 5): a 16-row MFMA fragment holds 8 GATE rows and the 8 UP rows of the same output columns
+// (the packed matrix interleaves gate / up in 16-row blocks, so each half is 8 contiguous memory rows = one 8-row DMA piece), a
+// workgroup owns TILES such fragments = 8 * TILES output columns, and SiLU(gate) * up pairs fragment rows i and i + 8.  That makes
+// the gate/up projection divisible in units of 8 columns instead of 16: at hidden 2048 (inter 6144: 384 pair tiles for 256 CUs --
+// a CU with two of them streams 2 x (128 KB of weights + the activations)) 256 workgroups x 3 half pairs give every CU 192 KB of
+// weights and ONE pass over the activations.  Same K slices, same reduction order per output element as the pair form.
+template <bool SPLIT, int TILES, int SH, int XMODE, int UNR, bool WLDS, bool QS = false, bool PALIAS = false, bool HP = false>
 __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   static_assert(!(SPLIT && XMODE >= 2), "the precise mode keeps fp32 activations");
+  static_assert(!HP || (WLDS && PALIAS && !QS && !SPLIT), "half-pair tiles: LDS-staged weights, aliased partial tile");
   static_assert(!WLDS || UNR % 2 == 0, "the LDS image is made of 64-wide k columns");
   static_assert(!QS || (TILES == 1 && SH == 1 && XMODE == 2 && WLDS), "quarter workgroups: bf16 fragment-order x, LDS-staged weights");
   constexpr int PIECES = QS ? 1 : 2;  // 8-row x 128-B DMA pieces per (tile, 64-wide k column)
@@ -93,8 +100,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   if (XMODE <= 1) { Q3A_ARG(a.x); Q3A_ARG(a.rms_w); }
   if (XMODE == 2) { Q3A_ARG(a.x16); Q3A_ARG(a.x16_frag); }
   if (XMODE == 3) { Q3A_ARG(a.xw16f); Q3A_ARG(a.ss_parts); Q3A_ARG(a.ss_nparts); }
-  if (TILES == 2) { Q3A_ARG(a.out16); Q3A_ARG(a.out16_frag); }
-  if (TILES == 1) { Q3A_ARG(a.next_w); Q3A_ARG(a.next_xw16f); Q3A_ARG(a.next_ss); }
+  if (TILES == 2 || HP) { Q3A_ARG(a.out16); Q3A_ARG(a.out16_frag); }
+  if (TILES == 1 && !HP) { Q3A_ARG(a.next_w); Q3A_ARG(a.next_xw16f); Q3A_ARG(a.next_ss); }
   if (QS) Q3A_ARG(a.qs_halves);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   Q3A_STAMP_AT(a.stamp, blockIdx.x, 0);  // entry
@@ -107,6 +114,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     n0 = part_row * 8;
   }
   const int lrow = QS ? (l15 & 7) : l15;  // fragment row -> weight row of the tile (QS: rows 8..15 duplicate 0..7, discarded)
+  // memory row of fragment row r16 of tile t.  Pair / plain form: consecutive rows.  HP: output columns c0 .. c0 + 7 of the tile;
+  // their gate rows start at (c0 / 16) * 32 + c0 % 16 in the interleaved matrix, the up rows 16 further on.
+  auto tile_row = [&](int t, int r16) -> int {
+    if (!HP) return n0 + t * 16 + r16;
+    const int c0 = (blockIdx.x * TILES + t) * 8;
+    return ((c0 >> 4) << 5) + (c0 & 15) + (r16 >> 3) * 16 + (r16 & 7);
+  };
   const int K = a.K;
   const int steps = K / 32, per = (steps + SK_WAVES - 1) / SK_WAVES;
   const int ks0 = wave * per, ks1 = min(steps, ks0 + per);
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   const uint16_t* wrow[TILES];
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
-    const int row = n0 + t * 16 + lrow;
+    const int row = tile_row(t, lrow);
     wrow[t] = a.W + (size_t)(row < a.N ? row : a.N - 1) * K + kc * kcw;
   }
   const float* xrow[SH];
@@ -146,7 +160,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   const int ep_i = QS ? (tid & 7) : (tid & 15), ep_s = QS ? hsel * 16 + ((tid >> 3) & 15) : (tid >> 4);
   const bool ep_live = QS ? (tid < 128 && ep_s < a.S) : (ep_s < a.S && (SH == 2 || ep_s < 16));
   float ep_resid = 0.f, ep_bias = 0.f, ep_nw = 0.f;
-  if (TILES == 1) {  // clamped addresses, no lane-divergent branch around the loads (the epilogue only uses them where live)
+  if (TILES == 1 && !HP) {  // clamped addresses, no lane-divergent branch around the loads (the epilogue only uses them where live)
     const int en = min(n0 + ep_i, a.N - 1), es = min(ep_s, a.S - 1);
     if (a.mode == 1) ep_resid = a.resid[(size_t)es * a.ldo + en];
     if (a.bias) ep_bias = a.bias[en];
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
         for (int col = 0; col < UNR / 2; ++col)
 #pragma unroll
           for (int g = 0; g < PIECES; ++g) {
-            const int r16 = g * 8 + rr, row = n0 + t * 16 + r16;
+            const int r16 = g * 8 + rr, row = tile_row(t, r16);
             const uint16_t* src = a.W + (size_t)(row < a.N ? row : a.N - 1) * K + (size_t)kb * 32 + col * 64 + (p ^ ((r16 >> 1) & 7)) * 8;
             __builtin_amdgcn_global_load_lds((sk_gptr_t)src, (sk_lptr_t)(wbase + ((t * (UNR / 2) + col) * PIECES + g) * 1024), 16, 0, QS ? 0 : 2);
           }
@@ -299,12 +313,17 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   const int i = ep_i, s = ep_s;
   const bool live_s = ep_live;  // (no early return: the row reduction below needs whole rows)
   const int sh = (QS || SH == 1 || !live_s) ? 0 : s >> 4, sj = s & 15;
-  float v[TILES];
+  float v[TILES], vu[HP ? TILES : 1];  // (HP: v = gate row i, vu = up row i + 8 of every tile; threads with i >= 8 idle along)
 #pragma unroll
   for (int t = 0; t < TILES; ++t) {
     v[t] = 0.f;
 #pragma unroll
-    for (int w = 0; w < SK_WAVES; ++w) v[t] += part(w, t, sh, i, sj);
+    for (int w = 0; w < SK_WAVES; ++w) v[t] += part(w, t, sh, HP ? (i & 7) : i, sj);
+    if (HP) {
+      vu[t] = 0.f;
+#pragma unroll
+      for (int w = 0; w < SK_WAVES; ++w) vu[t] += part(w, t, sh, (i & 7) + 8, sj);
+    }
   }
   if (XMODE == 1 || XMODE == 3) {
     float q = 0.f;
@@ -312,9 +331,26 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
     for (int w = 0; w < SK_WAVES; ++w) q += ssp[w][sh][sj];
     const float rstd = rstd_of(q / (float)K + a.eps, a.fast_math != 0);
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) v[t] *= rstd;
+    for (int t = 0; t < TILES; ++t) {
+      v[t] *= rstd;
+      if (HP) vu[t] *= rstd;
+    }
   }
-  if (TILES == 1) {
+  if (HP) {
+    if (!live_s || i >= 8) return;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const int c = (blockIdx.x * TILES + t) * 8 + i;  // output column; its gate / up rows in the interleaved matrix:
+      const int gr = ((c >> 4) << 5) + (c & 15), ur = gr + 16;
+      if (ur >= a.N) continue;
+      float g = v[t], u = vu[t];
+      if (a.bias) { g += a.bias[gr]; u += a.bias[ur]; }
+      const float y = silu_sel(g, a.fast_math != 0) * u;
+      if (a.out16) a.out16[a.out16_frag ? skinny_frag_index(s, c) : (size_t)s * a.ldo + c] = (uint16_t)f32_to_bf16_bits(y);
+      else a.out[(size_t)s * a.ldo + c] = y;
+    }
+    Q3A_STAMP_AT(a.stamp, blockIdx.x, 5);
+  } else if (TILES == 1) {
     const int n = n0 + i;
     const bool ok = live_s && n < a.N;
     float y = 0.f;
@@ -353,6 +389,20 @@ void launch_k(const SkinnyArgs& a, dim3 grid, hipStream_t s) {
   const int steps = a.K / 32, per = (steps + SK_WAVES - 1) / SK_WAVES;
   const size_t wbytes = (size_t)SK_WAVES * TILES * (UNR / 2) * 2048;
   static const bool wlds_on = [] { const char* e = getenv("Q3A_SKINNY_WLDS"); return !e || atoi(e) != 0; }();  // A/B knob
+  if constexpr (TILES == 2 && !SPLIT && XMODE == 3 && (UNR == 4 || UNR == 8)) {
+    // more pair tiles than CUs and the output columns divide into 3 half pairs per workgroup with at most one workgroup per CU
+    // (hidden 2048 / inter 6144: 256 workgroups): balanced half-pair form, the K slice in passes of 4 steps (96 KiB of LDS).
+    // glu_hp3: 1 = when it balances (default), 0 = never (A/B), 2 = whenever the shape allows (tests at small shapes)
+    static const int n_cu_hp = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    const int inter = a.N / 2;
+    const bool shape_ok = wlds_on && a.N % 32 == 0 && inter % 24 == 0 && per % 4 == 0 && steps % per == 0 && steps == per * SK_WAVES;
+    const bool balances = (int)grid.x > n_cu_hp && inter / 24 <= n_cu_hp;
+    if (shape_ok && (a.glu_hp3 == 2 || (a.glu_hp3 == 1 && balances))) {
+      const size_t wb = (size_t)SK_WAVES * 3 * 2 * 2048;  // 8 waves x 3 tiles x 2 k columns (4 steps) x 16 rows x 128 B
+      hipLaunchKernelGGL((skinny_kernel<false, 3, SH, 3, 4, true, false, true, true>), dim3(inter / 24), block, wb, s, a);
+      return;
+    }
+  }
   if constexpr (TILES == 2 && UNR % 4 == 0 && UNR >= 8 && !SPLIT && XMODE >= 2) {
     // more workgroups than CUs (gate/up at hidden 2048: 384): two passes of UNR / 2 steps with the partial tile aliased into the
     // weight region -> 64.5 KiB per workgroup, two resident per CU, no half-empty second round (A/B knob skinny_glu_2pass = 0 -> SkinnyArgs::glu_1pass)
@@ -415,6 +465,11 @@ hipError_t allow_glu_2pass() {  // the two-pass gate/up form: UNR = steps per pa
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_kernel<false, 2, SH, XMODE, UNR, true, false, true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, SK_WAVES * 2 * (UNR / 2) * 2048);
 }
+template <int SH>
+hipError_t allow_glu_hp3() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_kernel<false, 3, SH, 3, 4, true, false, true, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, SK_WAVES * 3 * 2 * 2048);
+}
 template <int XMODE, int UNR>
 hipError_t allow_big_lds_shapes() {
   hipError_t e = allow_big_lds<1, 1, XMODE, UNR>();
@@ -440,6 +495,8 @@ const char* skinny_init() {
   if (e == hipSuccess) e = allow_big_lds_shapes<0, 6>();
   if (e == hipSuccess) e = allow_big_lds_shapes<1, 4>();
   if (e == hipSuccess) e = allow_big_lds_shapes<1, 6>();
+  if (e == hipSuccess) e = allow_glu_hp3<1>();
+  if (e == hipSuccess) e = allow_glu_hp3<2>();
   if (e == hipSuccess) e = allow_glu_2pass<1, 2, 4>();
   if (e == hipSuccess) e = allow_glu_2pass<2, 2, 4>();
   if (e == hipSuccess) e = allow_glu_2pass<1, 3, 4>();

@@ -66,6 +66,7 @@ struct Knobs {
   std::atomic<int> eos_run_ahead{1};            // Q3A_EOS_RUN_AHEAD: decode steps kept enqueued ahead of the device in natural-EOS mode (1: no whole-batch step runs past the last EOS.  Paired on one engine, tools/eos_probe.py: 1 and 2 both +0.91 ms on the fixed-N run with 100 / 101 steps executed; bench.py's natural_eos leg: +0.2 ms (r4 builder box), -0.05 ms (r4 driver box) against a fixed-N run of the same engine)
   std::atomic<int> gemm16_ring{1};              // Q3A_GEMM16_RING: 3-4-stage LDS rings with counted vmcnt in the small-M GEMMs (0: two stages, one barrier per K tile)
   std::atomic<int> skinny_glu_2pass{1};         // Q3A_SKINNY_GLU_2PASS: gate/up skinny GEMM with more workgroups than CUs stages its K slice in two passes, partial tile aliased into the weight region: two workgroups per CU (k_skinny.hip PALIAS)
+  std::atomic<int> skinny_glu_hp3{1};           // Q3A_SKINNY_GLU_HP3: gate/up skinny GEMM as 3 half-pair tiles per workgroup when the pair form has more workgroups than CUs (k_skinny.hip HP; 0 = off, 2 = whenever the shape allows)
   std::atomic<int> fattn_pipe{0};               // Q3A_FATTN_PIPE: software-pipelined flash attention (k_fattn.hip fattn_pipe_kernel) instead of fattn_dma_kernel
   std::atomic<int> rope_variant{0};             // Q3A_ROPE_VARIANT (experiment): arithmetic form of qknorm_rope_kv_kernel (dev.h head_norm_rope)
   std::atomic<int> rope_twice{0};               // Q3A_DEBUG_ROPE_TWICE (debug): re-execute the trailing rows' rope kernel into shadow buffers and compare
@@ -220,6 +221,7 @@ struct SkinnyArgs {
   // N / 8 partial rows instead of N / 16 -- the caller sizes its buffers and the consumer's ss_nparts accordingly
   int qsplit;
   int qs_halves;  // (set by the launcher: 16-sequence halves per row tile)
+  int glu_hp3;    // gate/up as 256 workgroups x 3 half-pair tiles (k_skinny.hip HP): 1 = when that balances the CUs (set by the engine from knob skinny_glu_hp3), 0 = never, 2 = whenever the shape allows
   int glu_1pass;  // 1: keep the gate/up projection's single-pass form even when it has more workgroups than CUs (A/B; knob skinny_glu_2pass = 0)
   int fast_math;  // default mode: hardware rsq / exp / rcp in the RMSNorm scale and SiLU of the epilogue (dev.h rstd_of)
   Q3A_STAMP_FIELD

@@ -299,6 +299,46 @@ def test_quarter_workgroup_skinny_gemm_matches_full_tiles(tiny_dir):
         lib.q3a_debug_set(b"skinny_q", 1)
 
 
+def test_gate_up_skinny_gemm_forms_are_bit_identical():
+    """Batched decode step, gate/up projection (k_skinny.hip): the pair form (16 gate + 16 up rows per workgroup, one pass), the
+    two-pass pair form with the partial tile aliased into the weight region (knob skinny_glu_2pass; only taken when the pair form
+    has more workgroups than the GPU has CUs: the 1.7B dimensions) and the half-pair form (3 tiles of 8 gate + 8 up rows per
+    workgroup, knob skinny_glu_hp3: the default at the 1.7B dimensions, forced with 2 at the 0.6B dimensions) share K slices and
+    reduction order per output element: logits of two teacher-forced steps must agree BIT FOR BIT -- 32 sequences (two sequence
+    halves), 16 and 5 at the 0.6B dimensions, 16 at the 1.7B dimensions."""
+    from qwen3_asr_rs_amd import _lib
+    from qwen3_asr_rs_amd.distributed import pack_arena_host
+    lib = _lib.load()
+    clips = [synthetic.synthetic_clip(200 + i, 1.2 + 0.09 * (i % 9)) for i in range(32)]
+    cases = [(synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0), (32, 16, 5), (("pair", 0, 0), ("half pair", 2, 0))),
+             (synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b", "1.7b", seed=0, shards=2), (16,), (("pair", 0, 0), ("pair two-pass", 0, 1), ("half pair", 1, 1)))]
+    try:
+        for d, sizes, forms in cases:
+            arena = pack_arena_host(d).to("cuda:0")  # one upload per model, an engine per form on top of it
+            torch.cuda.synchronize()
+            for n in sizes:
+                got = {}
+                for name, hp3, two in forms:
+                    assert lib.q3a_debug_set(b"skinny_glu_hp3", hp3) == 0 and lib.q3a_debug_set(b"skinny_glu_2pass", two) == 0
+                    eng = HipEngine(d, 0, max_new_tokens=8, device_arena=(arena.data_ptr(), arena.numel()))
+                    eng.mel(clips[:n])
+                    eng.encode()
+                    prompts = [HipEngine.build_prompt(eng.num_audio_tokens(len(c))) for c in clips[:n]]
+                    eng.prefill(prompts, want_logits=False)
+                    eng.set_next_tokens([11 + 3 * i for i in range(n)])
+                    lg1, _, _ = eng.decode_step()
+                    lg2, nx, _ = eng.decode_step()
+                    got[name] = (lg1.copy(), lg2.copy(), nx.copy())
+                    eng.close()
+                for name, _, _ in forms[1:]:
+                    for a, b in zip(got["pair"], got[name]):
+                        assert np.isfinite(a).all() and np.array_equal(a, b), (d, n, name, float(np.abs(a.astype(np.float64) - b).max()))
+            del arena
+    finally:
+        lib.q3a_debug_set(b"skinny_glu_hp3", 1)
+        lib.q3a_debug_set(b"skinny_glu_2pass", 1)
+
+
 def test_mfma_attention_matches_valu_attention(tiny_dir):
     """Default mode: the MFMA flash-attention kernels against the fp32 VALU kernels on the same inputs
     (two windows in the encoder, ragged causal prefill)."""
