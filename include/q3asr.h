@@ -286,6 +286,10 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *                        (hidden 2048: 384) stages each wave's K slice in two passes and keeps the partial tile of the cross-wave
  *                        reduction inside the wave's weight region, so that two workgroups fit on a CU; 0: one pass, one workgroup
  *                        per CU, a full round and a half-empty one.  Same arithmetic.  Taken at the next prefill.
+ *   "dattn_pair_split"   0 / 1: when sequences x kv heads of a decode group would put a workgroup on at most half the CUs (16 sequences
+ *                        x 8 kv heads on 256 CUs), the batched decode attention runs TWO workgroups per (sequence, kv head) on alternate
+ *                        key tiles; the second to finish merges both partials inside the XCD's L2 (no waiting).  A merge that meets a
+ *                        partner placed on another XCD is counted and turns the call into an error.  Taken at the next prefill.
  *   "skinny_glu_hp3"     1 (default): when the gate/up projection of the batched decode step has more 32-row pair tiles than the GPU has
  *                        CUs and its output columns divide into 3 half-pair tiles (8 gate + 8 up rows in one MFMA fragment) per
  *                        workgroup with at most one workgroup per CU (hidden 2048 / inter 6144: 256 workgroups), it runs in that

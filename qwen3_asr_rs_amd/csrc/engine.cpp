@@ -118,6 +118,7 @@ Knobs& knobs() {
     env("Q3A_FATTN_PIPE", k.fattn_pipe);
     env("Q3A_SKINNY_GLU_2PASS", k.skinny_glu_2pass);
     env("Q3A_SKINNY_GLU_HP3", k.skinny_glu_hp3);
+    env("Q3A_DATTN_PAIR_SPLIT", k.dattn_pair_split);
     env("Q3A_ROPE_VARIANT", k.rope_variant);
     env("Q3A_DEBUG_ROPE_TWICE", k.rope_twice);
   });
@@ -167,6 +168,9 @@ struct q3a_engine {
   DevBuf enc_ctx16, dec_ctx16;  // opts.valu_attention in the default mode: bf16 copy of the fp32 attention context
   DevBuf dec_q16;
   DevBuf xcd_sync;  // arrival / departure words of the fused qkv + attention launch (one kv head per XCD)
+  DevBuf pair_sync; // pair-split batched decode attention (k_dattn.hip PAIR): [512 counters | 1024 XCC ids | error count], zeroed once
+  static constexpr int kPairCnt = 512, kPairXcc = 1024;
+  int n_cu = 256;
   DevBuf n_done;    // device counter of sequences that have produced their EOS (argmax_finalize)
   int* host_prog = nullptr;      // pinned host words written by argmax_finalize (FinalizeArgs::host_progress), polled without a sync
   int* host_prog_dev = nullptr;  // the same words as the device sees them
@@ -178,7 +182,7 @@ struct q3a_engine {
   int gsize = 32;  // sequences per group of the batched decode step (<= 32: one skinny-GEMM weight sweep), fixed per batch
   // knobs that shape the decode step, latched per batch in setup_prompts: producers outside the captured graph (prefill
   // finalize, set_tokens) and the captured step must agree on them, and the graph signature names them
-  int k_parallel_groups = 1, k_skinny_q = 1, k_fuse_qkv_attn = 0, k_dattn_batched_min_wgs = 128, k_skinny_glu_2pass = 1, k_skinny_glu_hp3 = 1;
+  int k_parallel_groups = 1, k_skinny_q = 1, k_fuse_qkv_attn = 0, k_dattn_batched_min_wgs = 128, k_skinny_glu_2pass = 1, k_skinny_glu_hp3 = 1, k_dattn_pair_split = 0;
   std::vector<hipStream_t> chain_streams;
   std::vector<hipEvent_t> join_ev;
   hipEvent_t fork_ev = nullptr;
@@ -288,6 +292,7 @@ struct q3a_engine {
     if (dev < 0 || dev >= n_dev) fail("device index out of range");
     HIPCHK(hipSetDevice(dev));
     KCHK(skinny_init());
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto& x : ev) HIPCHK(hipEventCreate(&x));
     HIPCHK(hipHostMalloc((void**)&host_prog, 64, hipHostMallocMapped));
@@ -710,9 +715,11 @@ struct q3a_engine {
       k_fuse_qkv_attn = kn.fuse_qkv_attn.load(); k_dattn_batched_min_wgs = kn.dattn_batched_min_wgs.load();
       k_skinny_glu_2pass = kn.skinny_glu_2pass.load();
       k_skinny_glu_hp3 = kn.skinny_glu_hp3.load();
+      k_dattn_pair_split = kn.dattn_pair_split.load();
     }
     const size_t ng = (size_t)n_groups(b);  // groups of <= gsize sequences of the batched decode step
     if (!xcd_sync.p) { xcd_sync.ensure(2 * 8 * 64 * 4); HIPCHK(hipMemset(xcd_sync.p, 0, 2 * 8 * 64 * 4)); }  // (never inside a capture)
+    if (!pair_sync.p) { pair_sync.ensure((kPairCnt + kPairXcc + 16) * 4); HIPCHK(hipMemset(pair_sync.p, 0, (kPairCnt + kPairXcc + 16) * 4)); }
     nn_x.ensure(ng * 32 * H * 2); nn_ss.ensure((size_t)ng * (H / 8) * 32 * 4);  // room for the finer (8-column) partial rows whichever shape the knob selects later
     x_dec.ensure((size_t)b * H * 4); next_tok.ensure((size_t)b * 4); forced_tok.ensure((size_t)b * 4);
     out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
@@ -748,7 +755,7 @@ struct q3a_engine {
   // source for DevBuf members and fails when one is missing here.
   std::vector<DevBuf*> step_bufs() {
     return {&kcache, &vcache, &x_dec, &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits,
-            &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po, &nn_x, &nn_ss, &rope_cur, &rope_cos, &rope_sin, &xcd_sync, &n_done, &forced_tok};
+            &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po, &nn_x, &nn_ss, &rope_cur, &rope_cos, &rope_sin, &xcd_sync, &pair_sync, &n_done, &forced_tok};
   }
   std::vector<const DevBuf*> step_bufs() const {
     auto v = const_cast<q3a_engine*>(this)->step_bufs();
@@ -1025,6 +1032,13 @@ struct q3a_engine {
     if (S * d.n_kv >= k_dattn_batched_min_wgs) {
       // the group alone fills the chip: one workgroup per (sequence, kv head) walks all keys and writes the context itself
       if (b16) { da.out16 = reinterpret_cast<uint16_t*>(s_ctx_g(grp)); da.out_frag = 1; } else da.out = s_ctx_g(grp);
+      // at most half the CUs would get a workgroup (16 sequences x 8 kv heads on 256 CUs): two workgroups per (sequence, kv head)
+      if (k_dattn_pair_split != 0 && 2 * S * d.n_kv <= n_cu && d.n_kv == 8 && attn_nsplit >= 2 && (s0 + S) * d.n_kv <= kPairCnt) {
+        da.nsplit = attn_nsplit;
+        da.pair_cnt = pair_sync.as<unsigned>() + (size_t)s0 * d.n_kv;
+        da.pair_xcc = pair_sync.as<unsigned>() + kPairCnt + (size_t)s0 * d.n_kv * 2;
+        da.pair_err = pair_sync.as<unsigned>() + kPairCnt + kPairXcc;
+      }
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn_batched(da, S, kv_f32(), ks)); });
     } else {
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
@@ -1103,7 +1117,7 @@ struct q3a_engine {
     }
     char buf[256];
     snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d.%d.%d.%d/%d/%d/%p/%016llx", B, gsize, k_parallel_groups, k_skinny_q, k_fuse_qkv_attn,
-             k_dattn_batched_min_wgs, k_skinny_glu_2pass, k_skinny_glu_hp3, (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
+             k_dattn_batched_min_wgs, k_skinny_glu_2pass, k_skinny_glu_hp3 + 4 * k_dattn_pair_split, (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
     return buf;
   }
 
@@ -1259,6 +1273,15 @@ struct q3a_engine {
   // Fused qkv + attention launch (experimental knob): a wait on the in-XCD arrival counter that ran out means partial q/k/v
   // entered the attention -- the ids are wrong, so every way out of the engine fails instead of returning them.
   void check_fused_launch() {
+    if (k_dattn_pair_split && pair_sync.p) {  // pair-split attention: a merge that met a partial written on ANOTHER XCD read it through a different L2
+      unsigned bad = 0;
+      HIPCHK(hipMemcpy(&bad, pair_sync.as<unsigned>() + kPairCnt + kPairXcc, 4, hipMemcpyDeviceToHost));
+      if (bad) {
+        HIPCHK(hipMemset(pair_sync.p, 0, (kPairCnt + kPairXcc + 16) * 4));
+        fail("pair-split decode attention: " + std::to_string(bad) + " merge(s) met a partner on another XCD (workgroup placement is not id % 8); "
+             "the generated ids are invalid -- run with q3a_debug_set(\"dattn_pair_split\", 0)");
+      }
+    }
     if (!k_fuse_qkv_attn || !xcd_sync.p) return;
     unsigned w[8 * 64];
     HIPCHK(hipMemcpy(w, xcd_sync.p, sizeof(w), hipMemcpyDeviceToHost));
@@ -1300,7 +1323,7 @@ struct q3a_engine {
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
                       &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
                       &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po,
-                      &enc_ctx16, &dec_ctx16, &dec_q16, &xcd_sync, &zero_page, &rope_cur, &nn_x, &nn_ss, &n_done, &dbg_scratch, &dbg_k2, &dbg_v2, &dbg_q2, &dbg_f1, &dbg_f2, &dbg_rope_log};
+                      &enc_ctx16, &dec_ctx16, &dec_q16, &xcd_sync, &pair_sync, &zero_page, &rope_cur, &nn_x, &nn_ss, &n_done, &dbg_scratch, &dbg_k2, &dbg_v2, &dbg_q2, &dbg_f1, &dbg_f2, &dbg_rope_log};
     for (auto* b : bufs) b->release();
     for (auto& kv : taps) kv.second.release();
     if (own_arena && arena) (void)hipFree(arena);
@@ -1755,6 +1778,7 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (strcmp(key, "fattn_pipe") == 0) { kn.fattn_pipe = value; return 0; }
   if (strcmp(key, "skinny_glu_2pass") == 0) { kn.skinny_glu_2pass = value; return 0; }
   if (strcmp(key, "skinny_glu_hp3") == 0) { kn.skinny_glu_hp3 = value; return 0; }
+  if (strcmp(key, "dattn_pair_split") == 0) { kn.dattn_pair_split = value; return 0; }
   if (strcmp(key, "rope_variant") == 0) { kn.rope_variant = value; return 0; }
   if (strcmp(key, "rope_twice") == 0) { kn.rope_twice = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";

@@ -414,7 +414,16 @@ __global__ __launch_bounds__(DA_WAVES * 64) void qkv_attn_kernel(DecodeAttnArgs 
 #ifndef Q3A_DATTN_RING
 #define Q3A_DATTN_RING 2  // tiles in flight per wave (A/B: 2 = one tile ahead 15.3 us per layer at 32 x 500 keys, 3 = 16.6 us)
 #endif
-template <int GROUP, typename KVT, int TILE = 128, int RING_T = Q3A_DATTN_RING>
+// PAIR (round 5): grid (kv head, sequence, 2).  With 16 sequences x 8 kv heads only 128 of 256 CUs had a workgroup; now workgroup
+// z of a (sequence, kv head) walks the key tiles t = z, z + 2, ... and the two are merged by whichever finishes second: each stores
+// its unnormalised (m, l, o) to pm / pl / po, waits for the stores to reach the L2, and counts itself in with an L2-resolved RMW; the
+// one that reads 1 takes the partner's partial, merges, normalises, writes the context and returns the counter to 0.  No waiting,
+// so no deadlock by construction.  Both workgroups of a pair have blockIdx.x = kv head and the dispatcher places workgroup i on XCD
+// i % 8 (linear id = x + 8 (y + S z), x < 8), so they share an L2 and the hand-off needs no L2 write-back (HISTORY 3.2: 0.3 us
+// inside an XCD, 3-4 us across); each partial carries its XCC_ID and a merge that meets another XCD's counts an error the engine
+// turns into a failure (never a silent wrong context).  The tile that holds position `pos` belongs to one of the two: that one
+// appends the new k / v rows.
+template <int GROUP, typename KVT, int TILE = 128, int RING_T = Q3A_DATTN_RING, bool PAIR = false>
 __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(DecodeAttnArgs a) {
   constexpr int DPL = Frag16<KVT>::DPL;
   constexpr int LPK = 128 / DPL;
@@ -432,7 +441,10 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   // of the first cache-row request
   Q3A_ARG(a.qkv); Q3A_ARG(a.pos); Q3A_ARG(a.q_norm); Q3A_ARG(a.k_norm); Q3A_ARG(a.eps); Q3A_ARG(a.rope_cur); Q3A_ARG(a.kcache); Q3A_ARG(a.vcache);
   Q3A_ARG(a.n_q); Q3A_ARG(a.n_kv); Q3A_ARG(a.max_ctx); Q3A_ARG(a.scale_div); Q3A_ARG(a.out); Q3A_ARG(a.out16); Q3A_ARG(a.out_frag);
+  if (PAIR) { Q3A_ARG(a.pm); Q3A_ARG(a.pl); Q3A_ARG(a.po); Q3A_ARG(a.pair_cnt); Q3A_ARG(a.pair_xcc); Q3A_ARG(a.pair_err); }
   const int kvh = blockIdx.x, s = blockIdx.y;
+  const int zh = PAIR ? (int)blockIdx.z : 0;   // which half of the key tiles
+  constexpr int TSTEP = PAIR ? 2 : 1;          // my j-th tile is tile zh + TSTEP * j
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int stamp_wg = blockIdx.y * gridDim.x + blockIdx.x;
   Q3A_STAMP_AT(a.stamp, stamp_wg, 0);  // entry
@@ -455,7 +467,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   // NI rows of a lane are KPI * 256 B apart (immediate offsets).  Rows beyond pos hold stale data and are masked below.
   const int last_tile = a.max_ctx / TILE - 1;
   const size_t lane_off = (size_t)key_w * 128 + sub * DPL;
-  auto load_tile = [&](int t, uint4 (&kr)[NI], uint4 (&vr)[NI]) {
+  auto load_tile = [&](int j, uint4 (&kr)[NI], uint4 (&vr)[NI]) {
+    const int t = zh + TSTEP * j;
     const size_t base = (size_t)min(t, last_tile) * (TILE * 128) + lane_off;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -486,7 +499,9 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   if constexpr (RING > 3) load_tile(3, kr3, vr3);
   __builtin_amdgcn_sched_barrier(0);
   Q3A_STAMP_AT(a.stamp, stamp_wg, 1);  // q/k/v row + first tiles requested
-  const int n_tiles = pos / TILE + 1;  // tiles that hold at least one key <= pos
+  const int n_all = pos / TILE + 1;  // tiles that hold at least one key <= pos
+  const int n_tiles = PAIR ? (n_all - zh + 1) / 2 : n_all;  // ... of which mine (PAIR: may be 0 for the odd half of a short context)
+  const bool own_pos = !PAIR || (((pos / TILE) & 1) == zh);  // my tiles include the one that receives the new token's k / v rows
 
   if (wave <= GROUP) {  // per-head RMSNorm + RoPE (as dev.h head_norm_rope)
     const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
@@ -498,13 +513,17 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
     q_s[wave][lane] = x1;
     q_s[wave][lane + 64] = x2;
   } else if (wave == GROUP) {
-    KvIo<KVT>::store(kc + (size_t)pos * 128 + lane, x1);
-    KvIo<KVT>::store(kc + (size_t)pos * 128 + lane + 64, x2);
+    if (own_pos) {
+      KvIo<KVT>::store(kc + (size_t)pos * 128 + lane, x1);
+      KvIo<KVT>::store(kc + (size_t)pos * 128 + lane + 64, x2);
+    }
     KvIo<KVT>::store(&k_s[lane], x1);
     KvIo<KVT>::store(&k_s[lane + 64], x2);
   } else if (wave == GROUP + 1) {
-    KvIo<KVT>::store(vc + (size_t)pos * 128 + lane, x1);
-    KvIo<KVT>::store(vc + (size_t)pos * 128 + lane + 64, x2);
+    if (own_pos) {
+      KvIo<KVT>::store(vc + (size_t)pos * 128 + lane, x1);
+      KvIo<KVT>::store(vc + (size_t)pos * 128 + lane + 64, x2);
+    }
     KvIo<KVT>::store(&v_s[lane], x1);
     KvIo<KVT>::store(&v_s[lane + 64], x2);
   }
@@ -533,8 +552,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
     for (int e = 0; e < DPL / 2; ++e) acc[g][e] = f32x2_t{0.f, 0.f};
   }
 
-  auto consume = [&](int t, uint4 (&kraw)[NI], uint4 (&vraw)[NI]) {
-    const int key_base = t * TILE + key_w;
+  auto consume = [&](int j, uint4 (&kraw)[NI], uint4 (&vraw)[NI]) {
+    const int key_base = (zh + TSTEP * j) * TILE + key_w;
     float sc[NI][GROUP];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -636,12 +655,11 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   }
   __syncthreads();
   Q3A_STAMP_AT(a.stamp, stamp_wg, 4);  // wave partials in LDS
+  float M = -INFINITY, L = 0.f, o0 = 0.f, o1 = 0.f;  // (waves < GROUP) this workgroup's unnormalised result for head g = wave
   if (wave < GROUP) {
     const int g = wave;
-    float M = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < DA_WAVES; ++w) M = fmaxf(M, cm[w][g]);  // finite: key 0 <= pos always exists
-    float L = 0.f, o0 = 0.f, o1 = 0.f;
+    for (int w = 0; w < DA_WAVES; ++w) M = fmaxf(M, cm[w][g]);  // finite unless PAIR and none of my tiles is live (key 0 <= pos always exists)
 #pragma unroll
     for (int w = 0; w < DA_WAVES; ++w) {
       const float f = (cm[w][g] == -INFINITY) ? 0.f : expw(cm[w][g] - M);
@@ -649,6 +667,48 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
       o0 += co[w][g][lane] * f;
       o1 += co[w][g][lane + 64] * f;
     }
+  }
+  if constexpr (PAIR) {
+    __shared__ unsigned pair_old;
+    const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));  // HW_REG_XCC_ID[3:0]
+    const size_t slot = ((size_t)s * a.n_q + (size_t)kvh * GROUP);                          // + g, then * 2 + half
+    if (wave < GROUP) {
+      const size_t mine = (slot + wave) * 2 + zh;
+      a.po[mine * 128 + lane] = o0;
+      a.po[mine * 128 + lane + 64] = o1;
+      if (lane == 0) { a.pm[mine] = M; a.pl[mine] = L; }
+    }
+    if (tid == 64 * GROUP) a.pair_xcc[((size_t)s * a.n_kv + kvh) * 2 + zh] = my_xcc;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a store is acknowledged when the L2 has it
+    __syncthreads();
+    if (tid == 0) pair_old = __hip_atomic_fetch_add(a.pair_cnt + (size_t)s * a.n_kv + kvh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // RMW: executed in the L2
+    __syncthreads();
+    if (pair_old == 0) return;  // the partner finishes second and merges
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing of the partner's partial may come from this CU's L1
+    if (tid == 0) {
+      __hip_atomic_exchange(a.pair_cnt + (size_t)s * a.n_kv + kvh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ready for the next launch
+      const unsigned other_xcc = __hip_atomic_load(a.pair_xcc + ((size_t)s * a.n_kv + kvh) * 2 + (zh ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (other_xcc != my_xcc) atomicAdd(a.pair_err, 1u);
+    }
+    if (wave < GROUP) {
+      const size_t other = (slot + wave) * 2 + (zh ^ 1);
+      const float M2 = __hip_atomic_load(a.pm + other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float L2 = __hip_atomic_load(a.pl + other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float p0 = __hip_atomic_load(a.po + other * 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float p1 = __hip_atomic_load(a.po + other * 128 + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // merge in tile order (even half first) so that the result does not depend on which workgroup arrived second
+      const bool me_first = zh == 0;
+      const float Ma = me_first ? M : M2, Mb = me_first ? M2 : M, La = me_first ? L : L2, Lb = me_first ? L2 : L;
+      const float a0 = me_first ? o0 : p0, b0 = me_first ? p0 : o0, a1 = me_first ? o1 : p1, b1 = me_first ? p1 : o1;
+      const float Mt = fmaxf(Ma, Mb);
+      const float fa = (Ma == -INFINITY) ? 0.f : expw(Ma - Mt), fb = (Mb == -INFINITY) ? 0.f : expw(Mb - Mt);
+      L = La * fa + Lb * fb;
+      o0 = a0 * fa + b0 * fb;
+      o1 = a1 * fa + b1 * fb;
+    }
+  }
+  if (wave < GROUP) {
+    const int g = wave;
     o0 /= L;
     o1 /= L;
     const int head = kvh * GROUP + g;
@@ -743,6 +803,21 @@ const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f
   if (a.max_ctx % 128 != 0) return "decode_attn_batched: max_ctx must be a multiple of 128 (whole key tiles)";
   const int group = a.n_q / a.n_kv;
   dim3 grid(a.n_kv, S), block(DA_WAVES * 64);
+  if (a.pair_cnt) {  // two workgroups per (sequence, kv head), merged inside the XCD (engine: 2 S n_kv <= CUs, 8 kv heads)
+    if (a.n_kv != 8 || a.nsplit < 2 || !a.pm || !a.pl || !a.po || !a.pair_xcc || !a.pair_err) return "decode_attn_batched: pair split needs 8 kv heads, two partial slots per head and its sync words";
+    const dim3 grid2(a.n_kv, S, 2);
+#define Q3A_DAP(G)                                                                                                                        \
+  do {                                                                                                                                    \
+    if (kv_f32) hipLaunchKernelGGL((decode_attn_batched_kernel<G, float, 128, 1, true>), grid2, block, 0, s, a);                          \
+    else hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t, 128, Q3A_DATTN_RING, true>), grid2, block, 0, s, a);                 \
+  } while (0)
+    if (group == 1) Q3A_DAP(1);
+    else if (group == 2) Q3A_DAP(2);
+    else if (group == 4) Q3A_DAP(4);
+    else return "decode_attn_batched: GQA group must be 1, 2 or 4";
+#undef Q3A_DAP
+    return nullptr;
+  }
   // A/B knob Q3A_DATTN_TILE64=1: 64-key tiles with a 4-deep register ring (same bytes in flight, steadier request stream)
   static const bool tile64 = [] { const char* e = getenv("Q3A_DATTN_TILE64"); return e && atoi(e) != 0; }();
   // A/B knob Q3A_DATTN_RING4=1: four 128-key tiles in flight per wave (every key of a <= 512-key context requested up front)

@@ -66,6 +66,7 @@ struct Knobs {
   std::atomic<int> eos_run_ahead{1};            // Q3A_EOS_RUN_AHEAD: decode steps kept enqueued ahead of the device in natural-EOS mode (1: no whole-batch step runs past the last EOS.  Paired on one engine, tools/eos_probe.py: 1 and 2 both +0.91 ms on the fixed-N run with 100 / 101 steps executed; bench.py's natural_eos leg: +0.2 ms (r4 builder box), -0.05 ms (r4 driver box) against a fixed-N run of the same engine)
   std::atomic<int> gemm16_ring{1};              // Q3A_GEMM16_RING: 3-4-stage LDS rings with counted vmcnt in the small-M GEMMs (0: two stages, one barrier per K tile)
   std::atomic<int> skinny_glu_2pass{1};         // Q3A_SKINNY_GLU_2PASS: gate/up skinny GEMM with more workgroups than CUs stages its K slice in two passes, partial tile aliased into the weight region: two workgroups per CU (k_skinny.hip PALIAS)
+  std::atomic<int> dattn_pair_split{0};         // Q3A_DATTN_PAIR_SPLIT: batched decode attention as TWO workgroups per (sequence, kv head) when sequences x kv heads fills at most half the CUs (16 sequences), merged inside the XCD by the second to arrive
   std::atomic<int> skinny_glu_hp3{1};           // Q3A_SKINNY_GLU_HP3: gate/up skinny GEMM as 3 half-pair tiles per workgroup when the pair form has more workgroups than CUs (k_skinny.hip HP; 0 = off, 2 = whenever the shape allows)
   std::atomic<int> fattn_pipe{0};               // Q3A_FATTN_PIPE: software-pipelined flash attention (k_fattn.hip fattn_pipe_kernel) instead of fattn_dma_kernel
   std::atomic<int> rope_variant{0};             // Q3A_ROPE_VARIANT (experiment): arithmetic form of qknorm_rope_kv_kernel (dev.h head_norm_rope)
@@ -262,6 +263,12 @@ struct DecodeAttnArgs {
   float* out;                  // [S][n_q*128] fp32 (precise mode) ...
   uint16_t* out16;             // ... or bf16 (default mode), row-major or, with out_frag, in skinny_frag_index order
   int out_frag;
+  // pair split (k_dattn.hip, PAIR = true): two workgroups per (sequence, kv head), even / odd key tiles, merged by the second to
+  // arrive.  pair_cnt: zeroed words, one per (sequence, kv head), returned to zero by every launch; the partials go to pm / pl / po
+  // ([S][n_q][2] / [S][n_q][2][128]: nsplit >= 2); pair_err counts merges whose partner ran on another XCD (result invalid).
+  unsigned* pair_cnt;
+  unsigned* pair_xcc;          // [S][n_kv][2] XCC_ID of the workgroup that wrote each partial
+  unsigned* pair_err;
   Q3A_STAMP_FIELD
 };
 #ifndef Q3A_DATTN_SPLIT_KEYS

@@ -339,6 +339,51 @@ def test_gate_up_skinny_gemm_forms_are_bit_identical():
         lib.q3a_debug_set(b"skinny_glu_2pass", 1)
 
 
+def test_pair_split_decode_attention_matches_one_workgroup_per_head():
+    """Batched decode attention with TWO workgroups per (sequence, kv head) on alternate key tiles, merged by the second to arrive
+    inside the XCD (knob dattn_pair_split; taken when sequences x kv heads fills at most half the CUs: 16 sequences x 8 kv heads)
+    against one workgroup per (sequence, kv head): 0.6B dimensions, 16 utterances whose contexts span 1 key tile (the odd half is
+    empty), 2-4 tiles and 8 tiles (a 75 s clip), three teacher-forced steps (one crosses into a new key tile for the 30 s clip
+    family: P = 405 -> keys 0..407 stay in tile 3; the 9.05 s clip goes 132 -> 135 keys).  Only the order of the final merge
+    differs: logits agree to fp32 rounding through 28 layers of bf16 context, greedy ids are equal; the placement check (both
+    workgroups of a pair on one XCD) must not have fired."""
+    from qwen3_asr_rs_amd import _lib
+    from qwen3_asr_rs_amd.distributed import pack_arena_host
+    lib = _lib.load()
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b_peaked", "0.6b", seed=0, embed_scale=synthetic.PEAKED_EMBED_SCALE)
+    secs = [75.0, 30.0, 30.0, 9.05, 1.5, 2.0, 3.1, 7.0, 12.4, 16.9, 21.0, 25.5, 28.0, 5.5, 19.2, 8.3]
+    clips = [synthetic.synthetic_clip(300 + i, sec) for i, sec in enumerate(secs)]
+    arena = pack_arena_host(d).to("cuda:0")
+    torch.cuda.synchronize()
+    got = {}
+    try:
+        for pair in (0, 1):
+            assert lib.q3a_debug_set(b"dattn_pair_split", pair) == 0
+            eng = HipEngine(d, 0, max_new_tokens=8, device_arena=(arena.data_ptr(), arena.numel()))
+            eng.mel(clips)
+            eng.encode()
+            prompts = [HipEngine.build_prompt(eng.num_audio_tokens(len(c))) for c in clips]
+            eng.prefill(prompts, want_logits=False)
+            steps = []
+            for k in range(3):
+                eng.set_next_tokens([23 + 5 * i + k for i in range(len(clips))])
+                lg, nx, _ = eng.decode_step()   # (its error check covers the pair placement)
+                steps.append((lg.copy(), nx.copy()))
+            got[pair] = steps
+            # free-running through the graph-replayed loop as well (fetch_ids runs the placement check too)
+            ids = eng.transcribe_batch(clips, None, max_new=6, fixed_new_tokens=6)
+            got[(pair, "ids")] = ids
+            eng.close()
+    finally:
+        lib.q3a_debug_set(b"dattn_pair_split", 0)
+    for (l0, n0), (l1, n1) in zip(got[0], got[1]):
+        assert np.isfinite(l1).all()
+        assert rel_l2(l1, l0) <= 2e-3, rel_l2(l1, l0)
+        assert (n0 == n1).mean() >= 0.9
+    same = sum(a == b for a, b in zip(got[(0, "ids")], got[(1, "ids")]))
+    assert same >= 14, same
+
+
 def test_mfma_attention_matches_valu_attention(tiny_dir):
     """Default mode: the MFMA flash-attention kernels against the fp32 VALU kernels on the same inputs
     (two windows in the encoder, ragged causal prefill)."""

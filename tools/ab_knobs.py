@@ -41,7 +41,7 @@ def main():
                 kv[k] = int(v)
         parsed.append((sset, kv))
     # defaults of every key that some setting touches (restored between settings)
-    known = {"skinny_glu_2pass": 1, "skinny_glu_hp3": 1, "dattn_batched_min_wgs": 128, "fattn_pipe": 0, "skinny_q": 1, "gemm256_resid_prefetch": 1, "gemm16_ring": 1,
+    known = {"skinny_glu_2pass": 1, "skinny_glu_hp3": 1, "dattn_pair_split": 0, "dattn_batched_min_wgs": 128, "fattn_pipe": 0, "skinny_q": 1, "gemm256_resid_prefetch": 1, "gemm16_ring": 1,
              "decode_group_size": 0, "decode_parallel_groups": 1, "fuse_qkrope": 1, "gemm256_min_tiles": 128}
     for _, kv in parsed:
         for k in kv:
