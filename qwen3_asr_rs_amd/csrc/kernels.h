@@ -63,7 +63,7 @@ struct Knobs {
   std::atomic<int> fuse_qkrope{1};              // Q3A_FUSE_QKROPE: QK-norm + RoPE + cache append as the qkv GEMM's epilogue
   std::atomic<int> skinny_q{1};                 // Q3A_SKINNY_Q: quarter workgroups for the o / down projections
   std::atomic<int> fuse_qkv_attn{0};            // Q3A_FUSE_QKV_ATTN: one-sequence decode qkv projection + attention in one launch
-  std::atomic<int> eos_run_ahead{1};            // Q3A_EOS_RUN_AHEAD: decode steps kept enqueued ahead of the device in natural-EOS mode (1: no whole-batch step runs past the last EOS.  Paired on one engine, tools/eos_probe.py: 1 and 2 both +0.91 ms on the fixed-N run with 100 / 101 steps executed; bench.py's natural_eos leg: +0.2 ms (r4 builder box), -0.05 ms (r4 driver box) against a fixed-N run of the same engine)
+  std::atomic<int> eos_run_ahead{1};            // Q3A_EOS_RUN_AHEAD: decode steps kept enqueued ahead of the device in natural-EOS mode.  1: exactly the steps needed are executed; paired with a fixed-N run of the same engine (profiles/r5_eos_run_ahead_ab.txt, two processes): 1 costs +0.03 / +1.24 ms per 100 tokens, 2 costs +2.07 / +1.86 ms (one wasted step + the same launch latency), 3 +1.3 / +1.2, 4 +3.3 / +3.1
   std::atomic<int> gemm16_ring{1};              // Q3A_GEMM16_RING: 3-4-stage LDS rings with counted vmcnt in the small-M GEMMs (0: two stages, one barrier per K tile)
   std::atomic<int> skinny_glu_2pass{1};         // Q3A_SKINNY_GLU_2PASS: gate/up skinny GEMM with more workgroups than CUs stages its K slice in two passes, partial tile aliased into the weight region: two workgroups per CU (k_skinny.hip PALIAS)
   std::atomic<int> dattn_pair_split{0};         // Q3A_DATTN_PAIR_SPLIT: batched decode attention as TWO workgroups per (sequence, kv head) when sequences x kv heads fills at most half the CUs (16 sequences), merged inside the XCD by the second to arrive
