@@ -7,7 +7,8 @@ tests nothing at the real dimensions exercised
   * more than 8 encoder windows at head dim 64 on fattn_dma_kernel (a 150 s clip: T = 1950 tokens in 19 windows),
   * a causal prefill of ~2000 rows on the 3-stage LDS ring (P = 1965),
   * the one-sequence decode attention beyond 8 key splits, across the 1024- and 2048-key marks (17 splits, merged inside
-    the o_proj GEMV), and the batched decode attention walking 16 key tiles for one utterance and 1-4 for its neighbours.
+    the o_proj GEMV), the two-sequence path beyond the GEMV's merge table (two 330 s clips: 34 key splits, separate merge launch),
+    and the batched decode attention walking 16 key tiles for one utterance and 1-4 for its neighbours.
 Same acceptance rule as tests/test_gpu_configs.py (oracle teacher-forced on the engine's own history, exact ids over the
 margin, every flip inside the pair condition), logit error bound LOGIT_TOL.
 
@@ -91,6 +92,32 @@ def test_one_sequence_decode_across_1024_and_2048_keys_0p6b_dims():
         assert [int(t[0]) for t in T] == ids, "stage-API decode differs from the hipGraph-replayed decode"
         margin_report(f"one sequence across {cross} keys (P = {P}, {N} tokens)", ids, [l[0] for l in L], ref)
         eng.close()
+
+
+def test_two_five_minute_clips_separate_split_merge_launch_0p6b_dims():
+    """Two 330 s clips as one batch (T = 4290 audio tokens in 42 windows, P = 4305): the two-sequence GEMV decode path with 34 live key
+    splits per head -- 2 x 16 x 34 = 1088 partial entries exceed the o_proj GEMV's merge table (GEMV_ATTN_MAX_TABLE = 1024,
+    csrc/k_gemv.hip), so the splits are merged by the separate attn_combine launch, a path no 30 s workload reaches (the reference
+    accepts any clip length: src/audio_encoder.rs:96-121, src/inference.rs:153).  Prefill of 8610 rows on the batch-sized kernels.
+    Default mode, 8 teacher-forced steps.  The two utterances are the SAME clip (the oracle's dense-mask encoder and 4305-row prefill
+    take about a minute of CPU per run: one run serves both; the engine must also give both the same ids)."""
+    d = _ckpt()
+    clip = synthetic.synthetic_clip(50, 330.0)
+    clips = [clip, clip.copy()]
+    N = 8
+    orc = O.AsrOracle(d)
+    eng = HipEngine(d, 0, max_new_tokens=N)
+    ids = eng.transcribe_batch(clips, None, max_new=N, fixed_new_tokens=N)
+    assert ids[0] == ids[1], "identical utterances of one batch must decode identically"
+    ref = orc.transcribe_ids(clip, forced_ids=ids[0][:N - 1], last_only=True)
+    refs = [ref, ref]
+    assert ref.num_audio_tokens == 4290 and ref.prompt_len == 4305
+    eng.mel(clips); eng.encode()
+    L, T = stepwise_logits(eng, [HipEngine.build_prompt(4290)] * 2, ids, N)
+    for b in range(2):
+        assert [int(t[b]) for t in T] == ids[b], f"utterance {b}: stage-API decode differs from the hipGraph-replayed decode"
+        margin_report(f"two 330 s clips, utterance {b} (P = 4305, 34 key splits, separate merge launch)", ids[b], [l[b] for l in L], refs[b])
+    eng.close()
 
 
 def test_batched_decode_attention_long_and_short_contexts_0p6b_dims():

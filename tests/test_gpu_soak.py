@@ -2,7 +2,7 @@
 weight arena, each driven by its own host thread, 32 clips of 30 s per batch.  Engine A repeats encoder + prefill + 2 tokens and
 every run must reproduce its own first (solo) run BIT FOR BIT in the last hidden rows -- the most sensitive observable: one wrong
 K-cache element anywhere in the 28 layers changes them -- and in the ids; the two load engines transcribe 100 tokens in a loop and
-every one of their batches must equal their solo ids.
+every one of their batches must equal their solo ids AND, bit for bit, the hidden rows of their last decode step (round 5).
 
 Round 3 saw 1 differing prefill in 10-30 here with the small-M GEMMs' LDS rings on (now the default) and 1 in 300 without: a
 packed fp32 instruction with an op_sel bit (hipcc's SLP output for the RoPE rotation, conv1, the split merge) returns a wrong low
@@ -35,7 +35,8 @@ def test_three_engines_32_clips_each_zero_differences():
     torch.cuda.synchronize()
     arena_arg = (arena.data_ptr(), arena.numel())
     A = HipEngine(d, 0, max_new_tokens=16, debug_taps=2, device_arena=arena_arg)  # 2: only the small taps (last hidden rows)
-    loads = [HipEngine(d, 0, max_new_tokens=100, device_arena=arena_arg) for _ in range(2)]
+    # (round 5: the load engines carry the light taps too -- their last decode step's lm_head input rows are bit-compared, not only their ids)
+    loads = [HipEngine(d, 0, max_new_tokens=100, debug_taps=2, device_arena=arena_arg) for _ in range(2)]
 
     def run_a():
         ids = A.transcribe_batch(clips, None, max_new=2, fixed_new_tokens=2)
@@ -46,17 +47,21 @@ def test_three_engines_32_clips_each_zero_differences():
         ids, last = run_a()
         assert ids == ref_ids and (last == ref_last).all()
     load_ref = loads[0].transcribe_batch(clips, None, max_new=100, fixed_new_tokens=100)
+    load_ref_rows = loads[0].debug_read("head_in").view(np.uint32).copy()  # residual rows the final norm + lm_head read in the LAST decode step
     assert loads[1].transcribe_batch(clips, None, max_new=100, fixed_new_tokens=100) == load_ref
+    assert (loads[1].debug_read("head_in").view(np.uint32) == load_ref_rows).all()
 
     stop = threading.Event()
-    load_batches, load_diff, errs = [0, 0], [0, 0], []
+    load_batches, load_diff, load_row_diff, errs = [0, 0], [0, 0], [0, 0], []
 
     def load(i):
         try:
             while not stop.is_set():
                 got = loads[i].transcribe_batch(clips, None, max_new=100, fixed_new_tokens=100)
+                rows = loads[i].debug_read("head_in").view(np.uint32)
                 load_batches[i] += 1
                 load_diff[i] += sum(u != r for u, r in zip(got, load_ref))
+                load_row_diff[i] += int((rows.reshape(B, -1) != load_ref_rows.reshape(B, -1)).any(axis=1).sum())
         except Exception as ex:  # noqa: BLE001
             errs.append(ex)
 
@@ -79,11 +84,13 @@ def test_three_engines_32_clips_each_zero_differences():
         for t in th: t.join()
     dt = time.perf_counter() - t0
     print(f"\n[soak] {done} prefills of {B} clips in {dt:.1f} s next to 2 load engines ({load_batches[0]} + {load_batches[1]} batches of {B} x 100 tokens): "
-          f"{len(bad_last)} prefills with differing last hidden rows, {len(bad_ids)} with differing ids, load-engine utterances differing {sum(load_diff)}")
+          f"{len(bad_last)} prefills with differing last hidden rows, {len(bad_ids)} with differing ids, load-engine utterances differing {sum(load_diff)} "
+          f"(ids) / {sum(load_row_diff)} (bits of the last decode step's hidden rows)")
     assert not errs, errs
     assert done >= MIN_PREFILLS
     assert not bad_last, bad_last[:8]
     assert not bad_ids, bad_ids[:8]
     assert sum(load_diff) == 0 and min(load_batches) >= 1, (load_diff, load_batches)
+    assert sum(load_row_diff) == 0, load_row_diff
     A.close()
     for e in loads: e.close()
