@@ -436,7 +436,17 @@ struct q3a_engine {
     io = q3a_io_timings{};
     io.mode = mode;
     HIPCHK(hipEventRecord(ev[0], stream));
-    if (mode == 0) {  // round 4's form (A/B)
+    const size_t total = (size_t)(pcm_off[b - 1] + ((ns[b - 1] + 3) & ~int64_t(3))) * 4;  // bytes of the device layout
+    bool staged = mode != 0;
+    if (staged && total > pin_cap) {  // (re)allocate the pinned mirror; a host that refuses to pin it gets the direct copies below
+      if (up_stream) HIPCHK(hipStreamSynchronize(up_stream));  // (a call that threw may have left copies in flight that read the old buffer)
+      if (pin_p) (void)hipHostFree(pin_p);
+      pin_p = nullptr; pin_cap = 0;
+      const size_t want = (total + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+      if (hipHostMalloc(&pin_p, want, hipHostMallocDefault) == hipSuccess && pin_p) pin_cap = want;
+      else { (void)hipGetLastError(); pin_p = nullptr; staged = false; io.mode = 0; }
+    }
+    if (!staged) {  // round 4's form (A/B knob Q3A_UPLOAD_MODE=0, or no pinned memory to be had)
       for (int u = 0; u < b; ++u)
         HIPCHK(hipMemcpyAsync(pcm.as<float>() + pcm_off[u], ptrs[u], (size_t)ns[u] * 4, hipMemcpyHostToDevice, stream));
       HIPCHK(hipStreamSynchronize(stream));
@@ -452,14 +462,6 @@ struct q3a_engine {
       HIPCHK(hipEventCreate(&up_t1));
     }
     HIPCHK(hipStreamSynchronize(up_stream));  // (a call that threw may have left copies in flight that read the staging buffer)
-    const size_t total = (size_t)(pcm_off[b - 1] + ((ns[b - 1] + 3) & ~int64_t(3))) * 4;  // bytes of the device layout
-    if (total > pin_cap) {
-      if (pin_p) (void)hipHostFree(pin_p);
-      pin_p = nullptr; pin_cap = 0;
-      const size_t want = (total + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
-      HIPCHK(hipHostMalloc(&pin_p, want, hipHostMallocDefault));
-      pin_cap = want;
-    }
     // pieces = runs of consecutive utterances of roughly equal bytes
     const int want_pieces = std::max(1, std::min(b, pieces_env));
     std::vector<int> first;  // first utterance of every piece (+ sentinel b)
