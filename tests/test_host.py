@@ -349,3 +349,37 @@ def test_step_buffers_cover_the_captured_step():
     # both guards really use the list
     assert "step_bufs()" in _cpp_function_body(src, "std::string make_graph_sig() const")
     assert "step_bufs()" in _cpp_function_body(src, "void setup_prompts(")
+
+
+def test_mfma_table_shapes_and_launch_matching():
+    """tools/mfma_table.py (the counter-vs-wall-clock MFMA table of DESIGN.md section 6): its shape list reproduces the tile counts
+    the committed profiles show for 32 clips (conv2 6000, conv3 1560, enc qkv 506 after the round split, fc1 686, 196-tile residual
+    shapes, dec qkv 768, gate/up 1224, o / down 204), leaves out launches below gemm256's tile threshold, and its matcher assigns a
+    launch sequence with same-grid neighbours (out / fc2, o / down) and foreign launches in between to the right shapes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mfma_table", os.path.join(ROOT, "tools", "mfma_table.py"))
+    mt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mt)
+    shp = mt.shapes("0.6b", 32)
+    grids = {}
+    for x in shp:
+        grids.setdefault(x["label"], x["grid"])
+    assert grids["conv2 implicit GEMM"] == 6000 and grids["conv3 implicit GEMM"] == 1560 and grids["enc qkv"] == 506
+    assert grids["enc fc1 (GELU)"] == 686 and grids["enc out (+residual)"] == 196 and grids["enc fc2 (+residual)"] == 196
+    assert grids["dec qkv + QK-norm/RoPE/KV epilogue"] == 768 and grids["dec gate/up (SwiGLU)"] == 1224 and grids["dec down (+residual)"] == 204
+    assert mt.split_rows(12480, 2688) == 46 * 256 and mt.split_rows(12480, 3584) == 0 and mt.split_rows(12960, 4096) == 48 * 256
+    assert "conv_out (+pos-emb, gather)" not in {x["label"] for x in mt.shapes("1.7b", 16)}   # 100 tiles < 128: not a gemm256 launch
+    names = {"ConvA256": "gemm256_kernel<false, ConvA256, false>", "DenseA256": "gemm256_kernel<false, DenseA256, false>",
+             "DenseA256, true": "gemm256_kernel<false, DenseA256, true>", "gemm256_kernel<true": "gemm256_kernel<true, DenseA256, false>"}
+    launches = []
+    for i, x in enumerate(shp * 2):
+        launches.append(dict(name=names[x["ksub"]], grid=x["grid"], dur=float(i)))
+        if i % 7 == 0:
+            launches.append(dict(name="gemm256_kernel<false, DenseA256, false>", grid=3, dur=0.0))   # a launch of some other shape
+        launches.append(dict(name="norm_kernel<false>", grid=12480, dur=0.0))
+    by, matched, unmatched = mt.classify(launches, shp)
+    assert matched == 2 * len(shp) and unmatched == len([i for i in range(2 * len(shp)) if i % 7 == 0])
+    per_pass = {lab: sum(1 for x in shp if x["label"] == lab) for lab in grids}
+    assert {lab: len(v) for lab, v in by.items()} == {lab: 2 * n for lab, n in per_pass.items()}
+    # same-grid neighbours keep their order: every "enc out" launch sits right before an "enc fc1" one in the sequence
+    assert all(d["dur"] % len(shp) in [i for i, x in enumerate(shp) if x["label"] == "enc out (+residual)"] for d in by["enc out (+residual)"])
