@@ -305,13 +305,13 @@ def test_gate_up_skinny_gemm_forms_are_bit_identical():
     has more workgroups than the GPU has CUs: the 1.7B dimensions) and the half-pair form (3 tiles of 8 gate + 8 up rows per
     workgroup, knob skinny_glu_hp3: the default at the 1.7B dimensions, forced with 2 at the 0.6B dimensions) share K slices and
     reduction order per output element: logits of two teacher-forced steps must agree BIT FOR BIT -- 32 sequences (two sequence
-    halves), 16 and 5 at the 0.6B dimensions, 16 at the 1.7B dimensions."""
+    halves), 16 and 5 at the 0.6B dimensions, 16 and 32 (BASELINE configs[3] / configs[4] per GPU) at the 1.7B dimensions."""
     from qwen3_asr_rs_amd import _lib
     from qwen3_asr_rs_amd.distributed import pack_arena_host
     lib = _lib.load()
     clips = [synthetic.synthetic_clip(200 + i, 1.2 + 0.09 * (i % 9)) for i in range(32)]
     cases = [(synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0), (32, 16, 5), (("pair", 0, 0), ("half pair", 2, 0))),
-             (synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b", "1.7b", seed=0, shards=2), (16,), (("pair", 0, 0), ("pair two-pass", 0, 1), ("half pair", 1, 1)))]
+             (synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b", "1.7b", seed=0, shards=2), (16, 32), (("pair", 0, 0), ("pair two-pass", 0, 1), ("half pair", 1, 1)))]
     try:
         for d, sizes, forms in cases:
             arena = pack_arena_host(d).to("cuda:0")  # one upload per model, an engine per form on top of it
