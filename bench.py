@@ -196,7 +196,10 @@ def algorithmic_bytes(dims, B, P, new_tokens):
     ctx_avg = P + (new_tokens - 1) / 2.0
     return {"qkv_gateup_gemv_per_launch": (2.0 * QKV * H + 4.0 * I * H) / 2.0,
             "weights_per_token": weights_per_token,
-            "decode_per_step": weights_per_token + B * kv_per_ctx_token * ctx_avg}
+            "decode_per_step": weights_per_token + B * kv_per_ctx_token * ctx_avg,
+            # per launch of the kernels that dominate the batched decode step (one launch per layer and step):
+            "batched_attention_per_launch": B * (kv_per_ctx_token / dims.dec_layers) * ctx_avg,   # K + V rows of every sequence, one layer
+            "gate_up_per_launch": 4.0 * I * H}                                                     # gate + up matrices, bf16
 
 
 def timed_region(eng, clips, steps, warmup, new_tokens, sync_all):
@@ -646,13 +649,21 @@ def main():
                                              "median of three consecutive child runs (profiled processes differ by 5-8 % on one box)",
                         avg_launch_us_of_the_three_child_runs=dom_runs, launches_per_token=2 * dims.dec_layers)
         elif dom is not None:
-            # batched configurations: report the dominant kernel's name/time; its algorithmic bytes are per-step figures
+            # batched configurations: the dominant kernel is the batched decode attention (KV stream) or a skinny GEMM (weight stream)
             kshort, kinfo = dom
             per_step_calls = kinfo["calls"] / (3.0 * max(args.new_tokens - 1, 1))
+            bpl, what = None, None
+            if kshort.startswith("decode_attn_batched_kernel"):
+                bpl, what = ab["batched_attention_per_launch"], "K + V cache rows of all sequences of one layer at the average context (SURVEY 8d: 114 688 B per context token and sequence over 28 layers at 0.6B)"
+            elif re.match(r"skinny_kernel<false, [23], ", kshort) and abs(per_step_calls - dims.dec_layers) < 0.5:
+                bpl, what = ab["gate_up_per_launch"], "gate + up projection matrices of one layer, bf16 (4 x inter x hidden bytes)"
             roof.update(kernel=kshort, avg_launch_us=round(kinfo["avg_us"], 3), launches_traced=kinfo["calls"],
                         share_of_kernel_time=round(kinfo["total_us"] / sum(v["total_us"] for v in trace.values()), 4),
-                        avg_launch_us_source="rocprofv3 --kernel-trace --stats, child run of this workload, in situ",
-                        bytes_per_launch=None, launches_per_token=round(per_step_calls, 2))
+                        avg_launch_us_source="rocprofv3 --kernel-trace --stats, child run of this workload, in situ; median of three consecutive child runs",
+                        avg_launch_us_of_the_three_child_runs=dom_runs,
+                        bytes_per_launch=round(bpl) if bpl else None, launches_per_token=round(per_step_calls, 2))
+            if what:
+                roof["bytes_per_launch_what"] = what
         elif stream_prof is not None:
             roof.update(kernel=gemv_name + " (decode qkv + gate/up GEMV)", bytes_per_launch=round(stream_prof["bytes_per_launch"]),
                         avg_launch_us=round(stream_prof["avg_us"], 3),
