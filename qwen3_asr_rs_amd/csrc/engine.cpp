@@ -196,6 +196,7 @@ struct q3a_engine {
   // 128-key split).  Sized by what the caches HOLD, not by their capacity: pos_hi_ = longest prompt + decode steps enqueued
   // (host-side count, an upper bound of every sequence's position), so a generous max_new_tokens costs no empty splits.
   int pos_hi_ = 0, live_nsplit_ = 0;
+  int min_P_ = 0;  // shortest prompt of the batch (decides DecodeAttnArgs::trim_prologue; part of the graph signature)
 
   // ---- input upload of q3a_transcribe_batch[_ptrs] (the window is host PCM -> ids on the host) ----
   // The caller's buffers are pageable: they are copied (several host threads for a batch-sized input) into a pinned
@@ -682,6 +683,7 @@ struct q3a_engine {
     max_new = std::min(std::max(max_new_req, 1), opts.max_new_tokens);
     max_ctx = ((maxP + max_new + 1 + 127) / 128) * 128;  // whole 128-key tiles (the batched decode attention reads cache rows tile by tile)
     pos_hi_ = maxP;
+    min_P_ = *std::min_element(P.begin(), P.end());
     {  // A/B knob: extra keys per (sequence, kv head) cache row block, so that the streams of the batched decode attention
        // do not all start a power of two apart (512 keys x 256 B = 128 KiB)
       static const int pad = [] { const char* e = getenv("Q3A_CTX_PAD"); return e ? atoi(e) : 0; }();
@@ -1034,6 +1036,7 @@ struct q3a_engine {
     if (S * d.n_kv >= k_dattn_batched_min_wgs) {
       // the group alone fills the chip: one workgroup per (sequence, kv head) walks all keys and writes the context itself
       if (b16) { da.out16 = reinterpret_cast<uint16_t*>(s_ctx_g(grp)); da.out_frag = 1; } else da.out = s_ctx_g(grp);
+      da.trim_prologue = min_P_ < 2 * 128;  // some sequence is shorter than the kernel's two prologue key tiles
       // at most half the CUs would get a workgroup (16 sequences x 8 kv heads on 256 CUs): two workgroups per (sequence, kv head)
       if (k_dattn_pair_split != 0 && 2 * S * d.n_kv <= n_cu && d.n_kv == 8 && attn_nsplit >= 2 && (s0 + S) * d.n_kv <= kPairCnt) {
         da.nsplit = attn_nsplit;
@@ -1119,7 +1122,7 @@ struct q3a_engine {
     }
     char buf[256];
     snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d.%d.%d.%d/%d/%d/%p/%016llx", B, gsize, k_parallel_groups, k_skinny_q, k_fuse_qkv_attn,
-             k_dattn_batched_min_wgs, k_skinny_glu_2pass, k_skinny_glu_hp3 + 4 * k_dattn_pair_split, (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
+             k_dattn_batched_min_wgs, k_skinny_glu_2pass, k_skinny_glu_hp3 + 4 * k_dattn_pair_split + 8 * (min_P_ < 256), (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
     return buf;
   }
 

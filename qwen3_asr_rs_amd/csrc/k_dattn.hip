@@ -440,7 +440,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   // every argument in one scalar-load clause (dev.h Q3A_ARG): the prologue had three scalar round trips in series in front
   // of the first cache-row request
   Q3A_ARG(a.qkv); Q3A_ARG(a.pos); Q3A_ARG(a.q_norm); Q3A_ARG(a.k_norm); Q3A_ARG(a.eps); Q3A_ARG(a.rope_cur); Q3A_ARG(a.kcache); Q3A_ARG(a.vcache);
-  Q3A_ARG(a.n_q); Q3A_ARG(a.n_kv); Q3A_ARG(a.max_ctx); Q3A_ARG(a.scale_div); Q3A_ARG(a.out); Q3A_ARG(a.out16); Q3A_ARG(a.out_frag);
+  Q3A_ARG(a.n_q); Q3A_ARG(a.n_kv); Q3A_ARG(a.max_ctx); Q3A_ARG(a.scale_div); Q3A_ARG(a.out); Q3A_ARG(a.out16); Q3A_ARG(a.out_frag); Q3A_ARG(a.trim_prologue);
   if (PAIR) { Q3A_ARG(a.pm); Q3A_ARG(a.pl); Q3A_ARG(a.po); Q3A_ARG(a.pair_cnt); Q3A_ARG(a.pair_xcc); Q3A_ARG(a.pair_err); }
   const int kvh = blockIdx.x, s = blockIdx.y;
   const int zh = PAIR ? (int)blockIdx.z : 0;   // which half of the key tiles
@@ -467,10 +467,9 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   // NI rows of a lane are KPI * 256 B apart (immediate offsets).  Rows beyond pos hold stale data and are masked below.
   const int last_tile = a.max_ctx / TILE - 1;
   const size_t lane_off = (size_t)key_w * 128 + sub * DPL;
-  // trim (round 5): a tile requested from INSIDE the loop -- `pos` has long arrived by then -- asks for row min(key, pos) instead of
-  // rows past the sequence's last key: those lanes then all hit the one line of row `pos` instead of streaming stale cache rows from
+  // trim (round 5): a tile asks for row min(key, pos) instead of rows past the sequence's last key: those lanes then all hit the one line of row `pos` instead of streaming stale cache rows from
   // HBM (they are masked either way).  The last tile of a context is half empty on average: 11 % of the bytes at 405-505 keys
-  // (PMC: 68.2 MB fetched per launch for 59.6 MB of live rows).  The prologue tiles stay unconditional: nothing there waits for `pos`.
+  // (PMC: 68.2 MB fetched per launch for 59.6 MB of live rows).
   auto load_tile = [&](int j, uint4 (&kr)[NI], uint4 (&vr)[NI], const bool trim = false, const int pos_row = 0) {
     const int t = zh + TSTEP * j;
     if (!trim) {
@@ -490,6 +489,17 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
       }
     }
   };
+#ifndef Q3A_DATTN_TRIM
+#define Q3A_DATTN_TRIM 2  // (A/B builds: 0 = every tile requested whole, 1 = only the tiles requested from inside the loop are trimmed)
+#endif
+  constexpr bool TRIM = Q3A_DATTN_TRIM != 0;
+  // The prologue's later tiles are trimmed only when the host says some sequence of the batch is shorter than the prologue
+  // (a.trim_prologue: shortest prompt < 2 tiles).  Their addresses then need `pos`, a second, dependent scalar load: measured
+  // +4 us per step at 32 x 30 s clips, where no sequence has a stale row there (1133-1136 vs 1129-1132 us), -4 % per step at 32 x
+  // 7 s clips, where tile 1 is stale for everyone (962 vs 1003 us) -- profiles/r5_ab_dattn_trim.txt.
+  const bool TRIM_PRO = Q3A_DATTN_TRIM >= 2 && a.trim_prologue != 0;
+  // (tile 0 goes out whole, the moment the arguments are in: `pos` is a second, dependent scalar load -- a.pos is one of the arguments --
+  // and waiting for it here would put its round trip in front of the first request.)
   load_tile(0, kr0, vr0);
   // the new token's q / k / v rows, norm weights and RoPE row go BETWEEN tile 0 and the rest of the ring: loads return in
   // order, so they are back right behind tile 0 -- when they are first needed -- and tile 0 is consumed (and the ring
@@ -508,9 +518,9 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
     }
   }
   __builtin_amdgcn_sched_barrier(0);  // (keeps the row requests in front of the following tiles)
-  if constexpr (RING > 1) load_tile(1, kr1, vr1);  // unconditional (clamped): nothing here waits for `pos`
-  if constexpr (RING > 2) load_tile(2, kr2, vr2);
-  if constexpr (RING > 3) load_tile(3, kr3, vr3);
+  if constexpr (RING > 1) load_tile(1, kr1, vr1, TRIM_PRO, pos);
+  if constexpr (RING > 2) load_tile(2, kr2, vr2, TRIM_PRO, pos);
+  if constexpr (RING > 3) load_tile(3, kr3, vr3, TRIM_PRO, pos);
   __builtin_amdgcn_sched_barrier(0);
   Q3A_STAMP_AT(a.stamp, stamp_wg, 1);  // q/k/v row + first tiles requested
   const int n_all = pos / TILE + 1;  // tiles that hold at least one key <= pos
@@ -625,10 +635,6 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
       }
     }
   };
-#ifndef Q3A_DATTN_TRIM
-#define Q3A_DATTN_TRIM 1  // (A/B builds: 0 = every in-loop tile requested whole)
-#endif
-  constexpr bool TRIM = Q3A_DATTN_TRIM != 0;
   for (int t = 0; t < n_tiles; t += RING) {
     consume(t, kr0, vr0);
     if (t + RING < n_tiles) load_tile(t + RING, kr0, vr0, TRIM, pos);

@@ -263,6 +263,7 @@ struct DecodeAttnArgs {
   float* out;                  // [S][n_q*128] fp32 (precise mode) ...
   uint16_t* out16;             // ... or bf16 (default mode), row-major or, with out_frag, in skinny_frag_index order
   int out_frag;
+  int trim_prologue;           // batched kernel: 1 = some sequence of the batch is shorter than the two prologue key tiles, trim them to the live rows too
   // pair split (k_dattn.hip, PAIR = true): two workgroups per (sequence, kv head), even / odd key tiles, merged by the second to
   // arrive.  pair_cnt: zeroed words, one per (sequence, kv head), returned to zero by every launch; the partials go to pm / pl / po
   // ([S][n_q][2] / [S][n_q][2][128]: nsplit >= 2); pair_err counts merges whose partner ran on another XCD (result invalid).
