@@ -68,3 +68,30 @@ def test_batched_requests_stay_batched_in_the_device_code():
     assert longest_load_run(r"gemv1_kernelILi1ELi4ELb0ELb1EEE") >= 26               # merge: 4 x (m, l, o0, o1) + ... in one batch
     assert longest_load_run(r"gemv1_kernelILi2ELi2ELb1ELb0EEE") >= 12               # qkv / gate-up: x, norm weight and the weight rows
     assert iw.exposed(["G", "W0", "j", "G", "G", "W0", "G", "G", "G", "W0"]) == 2   # the suspects metric itself
+
+
+@needs_hipcc
+def test_no_kernel_of_the_product_uses_scratch_memory():
+    """Every kernel of the library keeps its working set in registers and LDS: a kernel that starts to spill VGPRs (scratch =
+    private memory behind the vector cache) silently turns a register ring into memory traffic -- the pipelined flash attention
+    at three workgroups per CU needed 104 B of scratch and was rejected for it (docs/HISTORY.md, round 5).  Read from the AMDGPU
+    kernel metadata at the end of hipcc's device assembly; SGPR spills into VGPR lanes are allowed (no memory behind them)."""
+    import re
+    build.build(verbose=False)
+    seen, offenders, widest = 0, [], 0
+    for src in build.SOURCES:
+        if not src.endswith(".hip"):
+            continue
+        txt = open(build.isa_path(src)).read()
+        for blk in re.split(r"\n  - (?=\.agpr_count)", txt)[1:]:
+            field = lambda k: re.search(r"\." + k + r":\s+(\S+)", blk)  # noqa: E731
+            if not field("name"):
+                continue
+            seen += 1
+            scratch, vspill = int(field("private_segment_fixed_size").group(1)), int(field("vgpr_spill_count").group(1))
+            widest = max(widest, int(field("group_segment_fixed_size").group(1)))
+            if scratch or vspill:
+                offenders.append((src, field("name").group(1), scratch, vspill))
+    assert seen > 250, seen            # the metadata was really parsed (309 kernel instantiations in round 5)
+    assert not offenders, offenders
+    assert widest <= 160 * 1024        # static LDS of the widest kernel fits a CU
