@@ -411,6 +411,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void qkv_attn_kernel(DecodeAttnArgs 
 //     shifts + 4 packed FMAs -- this kernel is VALU-bound at batch 32;
 //   * each wave keeps running (max, sum, acc) over its 16 keys of every tile; the cross-lane / cross-wave folds happen
 //     once at the end.
+template <bool B> struct BoolC { static constexpr bool value = B; };  // compile-time flag passed to a generic lambda
 #ifndef Q3A_DATTN_RING
 #define Q3A_DATTN_RING 2  // tiles in flight per wave (A/B: 2 = one tile ahead 15.3 us per layer at 32 x 500 keys, 3 = 16.6 us)
 #endif
@@ -576,14 +577,18 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
     for (int e = 0; e < DPL / 2; ++e) acc[g][e] = f32x2_t{0.f, 0.f};
   }
 
-  auto consume = [&](int j, uint4 (&kraw)[NI], uint4 (&vraw)[NI]) {
+  // A tile is consumed in one of two forms (round 5, Q3A_DATTN_EDGE): every tile in front of the one that holds position `pos`
+  // has 128 live keys -- no new-token row to patch in, no stale row to blank, no score to mask -- and takes the INNER form,
+  // which has none of that (the patched form spent 64 of its ~430 VALU issues per tile on register copies and exec-masked
+  // moves alone: the in-place patch of the ring registers made hipcc copy the whole tile twice).  The choice is scalar (`pos`
+  // and the tile index are SGPRs), the arithmetic of an inner tile is the same instruction for instruction: bit-identical.
+  auto tile_body = [&](auto edge_c, int j, const uint4 (&kraw)[NI], const uint4 (&vraw)[NI]) {
+    constexpr bool EDGE = decltype(edge_c)::value;
     const int key_base = (zh + TSTEP * j) * TILE + key_w;
     float sc[NI][GROUP];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int key = key_base + i * KPI;
-      if (key == pos) { kraw[i] = k_new; vraw[i] = v_new; }
-      if (key > pos) vraw[i] = make_uint4(0u, 0u, 0u, 0u);  // stale cache row (possibly NaN bits): keep 0 * v finite
 #pragma unroll
       for (int g = 0; g < GROUP; ++g) {
         float p;
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
         }
         p = row16_sum(p);
         if (LPK == 32) p = xor16_sum(p);
-        sc[i][g] = (key <= pos) ? p * inv_scale : -INFINITY;  // layers.rs:327-328 scales after the matmul
+        sc[i][g] = (!EDGE || key <= pos) ? p * inv_scale : -INFINITY;  // layers.rs:327-328 scales after the matmul
       }
     }
 #pragma unroll
@@ -628,12 +633,33 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
       Frag16<KVT>::unpack(vraw[i], vf);
 #pragma unroll
       for (int g = 0; g < GROUP; ++g) {
-        const float p = (key <= pos) ? expw(sc[i][g] - mrun[g]) : 0.f;
+        const float p = (!EDGE || key <= pos) ? expw(sc[i][g] - mrun[g]) : 0.f;
         lrun[g] += p;
 #pragma unroll
-        for (int e = 0; e < DPL / 2; ++e) acc[g][e] += f32x2_t{p, p} * f32x2_t{vf[2 * e], vf[2 * e + 1]};
+        for (int e = 0; e < DPL / 2; ++e)  // explicit FMA: with two forms of the tile hipcc left one of the 32 contractions as multiply + add across a branch
+          acc[g][e] = __builtin_elementwise_fma(f32x2_t{p, p}, f32x2_t{vf[2 * e], vf[2 * e + 1]}, acc[g][e]);
       }
     }
+  };
+#ifndef Q3A_DATTN_EDGE
+#define Q3A_DATTN_EDGE 1  // (A/B builds: 0 = every tile in the patched form, as before)
+#endif
+  const int edge_tile = pos / TILE;  // the tile that holds position `pos`: the last one with a live key
+  auto consume = [&](int j, const uint4 (&kraw)[NI], const uint4 (&vraw)[NI]) {
+    if (Q3A_DATTN_EDGE && zh + TSTEP * j < edge_tile) {
+      tile_body(BoolC<false>{}, j, kraw, vraw);
+      return;
+    }
+    const int key_base = (zh + TSTEP * j) * TILE + key_w;
+    uint4 kp[NI], vp[NI];  // the tile with the new token's rows patched in and the rows past it blanked
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int key = key_base + i * KPI;
+      kp[i] = (key == pos) ? k_new : kraw[i];
+      vp[i] = (key == pos) ? v_new : vraw[i];
+      if (key > pos) vp[i] = make_uint4(0u, 0u, 0u, 0u);  // stale cache row (possibly NaN bits): keep 0 * v finite
+    }
+    tile_body(BoolC<true>{}, j, kp, vp);
   };
   for (int t = 0; t < n_tiles; t += RING) {
     consume(t, kr0, vr0);
@@ -842,15 +868,12 @@ const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f
 #undef Q3A_DAP
     return nullptr;
   }
-  // A/B knob Q3A_DATTN_TILE64=1: 64-key tiles with a 4-deep register ring (same bytes in flight, steadier request stream)
-  static const bool tile64 = [] { const char* e = getenv("Q3A_DATTN_TILE64"); return e && atoi(e) != 0; }();
-  // A/B knob Q3A_DATTN_RING4=1: four 128-key tiles in flight per wave (every key of a <= 512-key context requested up front)
-  static const bool ring4 = [] { const char* e = getenv("Q3A_DATTN_RING4"); return e && atoi(e) != 0; }();
+  // (Round 5 measured two more shapes of the ring here -- 64-key tiles x 4 in flight, 128-key tiles x 4 in flight -- behind
+  // environment switches; both lost at 16 and 32 sequences (profiles/r5_ab_dattn_ring_16seq.txt) and their instantiations are gone:
+  // the template still takes TILE and RING_T.)
 #define Q3A_DAB(G)                                                                                          \
   do {                                                                                                      \
     if (kv_f32) hipLaunchKernelGGL((decode_attn_batched_kernel<G, float>), grid, block, 0, s, a);          \
-    else if (tile64) hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t, 64, 4>), grid, block, 0, s, a); \
-    else if (ring4) hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t, 128, 4>), grid, block, 0, s, a); \
     else hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t>), grid, block, 0, s, a);              \
   } while (0)
   if (group == 1) Q3A_DAB(1);

@@ -13,6 +13,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -85,7 +86,8 @@ def main():
                           "audio_s_per_s": round(args.batch * args.seconds / ms * 1e3, 1),
                           "encoder_ms": round(st["encoder_ms"], 3), "prefill_ms": round(st["prefill_ms"], 3), "decode_ms": round(st["decode_ms"], 3),
                           "decode_us_per_step": round(st["decode_ms"] * 1e3 / max(int(st["decode_steps"]), 1), 2),
-                          "ids_equal_to_first_setting": same, "utterances_differing": ndiff}), flush=True)
+                          "ids_equal_to_first_setting": same, "utterances_differing": ndiff,
+                          "ids_crc32": zlib.crc32(repr(r["ids"]).encode())}), flush=True)  # (compare across processes / Q3A_LIB builds)
 
 
 if __name__ == "__main__":
