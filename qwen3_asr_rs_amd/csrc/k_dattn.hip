@@ -408,7 +408,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void qkv_attn_kernel(DecodeAttnArgs 
 //   * the next tile's cache rows are requested before the current tile is consumed (register double buffer);
 //   * bf16 cache: q is rounded to bf16 pairs once (the rounding the MFMA prefill attention applies to q as well) and the
 //     scores use v_dot2c_f32_bf16 on the RAW cache dwords: 4 instructions per 8 dims and head instead of 8 unpack
-//     shifts + 4 packed FMAs -- this kernel is VALU-bound at batch 32;
+//     shifts + 4 packed FMAs -- this kernel was thought VALU-bound at batch 32 (round 5: a form with 39 % fewer issues per tile bought 2 %);
 //   * each wave keeps running (max, sum, acc) over its 16 keys of every tile; the cross-lane / cross-wave folds happen
 //     once at the end.
 template <bool B> struct BoolC { static constexpr bool value = B; };  // compile-time flag passed to a generic lambda
