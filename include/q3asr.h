@@ -214,6 +214,18 @@ int32_t q3a_profile_decode_step(q3a_engine* e, q3a_kernel_profile* out);
  * Needs decode state with <= 2 sequences (the GEMV path); does not change it. */
 int32_t q3a_profile_weight_stream(q3a_engine* e, int32_t reps, float* avg_us, double* bytes_per_launch, int32_t* launches);
 
+/* Measured denominators for the roofline fractions (SURVEY.md section 8d "Peaks to divide by: measure on the box"; csrc/k_peaks.hip):
+ * a read-only HBM stream over 2 GiB (the access pattern of the decode-step weight streams), a 1 GiB device copy and a triad
+ * (bytes counted on every stream they touch), and the library's own 256x256x64 bf16 GEMM on 8192^3 -- each the best of `reps`
+ * launches between two HIP events.  Needs 2 GiB of free device memory; not on the product path. */
+typedef struct q3a_peaks {
+  double hbm_read_gbps, hbm_copy_gbps, hbm_triad_gbps; /* GB/s (1e9 bytes per second) */
+  double hbm_read_bytes;                                /* bytes one read sweep covers */
+  double mfma_bf16_tflops;                              /* 2 M N K / time */
+  int32_t gemm_m, gemm_n, gemm_k, n_cu, reps, reserved[3];
+} q3a_peaks;
+int32_t q3a_measure_peaks(int32_t device, int32_t reps, q3a_peaks* out);
+
 /* Debug taps (opts.debug_taps=1): copy a named intermediate to host. `bytes` = capacity of dst;
  * *actual receives the tap size. Names: mel conv1 conv2 conv3 enc_in enc_layer0 enc_last
  * audio_embeds dec_embed dec_layer0 dec_last_hidden logits. */
@@ -267,41 +279,16 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *                        GEMM; 0: as the separate kernel (taken at the next prefill).
  *   "skinny_q"           1 (default): o / down projections of the batched decode step as 8-row x 16-sequence workgroups;
  *                        0: 16 rows x 32 sequences (taken at the next engine / batch set-up: it sizes a buffer).
- *   "fuse_qkv_attn"      0 (default) / 1: one-sequence decode runs the qkv projection and the attention key splits as ONE launch
- *                        handed over inside each XCD (8 kv heads x 2 query heads only); taken at the next prefill.
  *   "eos_run_ahead"      decode steps the natural-EOS greedy loop keeps enqueued ahead of the device (default 1): the stop
  *                        condition is evaluated on the device and read from pinned host memory without synchronising.
- *   "live_key_splits"    1 (default): the one-sequence decode attention launches as many 128-key splits as the caches HOLD keys
- *                        for (longest prompt + steps so far; the count is part of the graph signature), so max_new_tokens is a
- *                        capacity, not a cost; 0: as many as the caches have room for.
- *   "gemm16_ring"        1 (default since round 4): the small-M GEMMs of a one-clip encoder / prefill stage K tiles through rings
- *                        of 3-4 LDS stages with counted vmcnt (encoder + prefill of a 30 s clip 4.1 -> 3.8 ms); 0: two LDS buffers,
- *                        one barrier per K tile.  (Round 3 kept this off because it raised the rate of a rare run-to-run difference
- *                        with several engines busy on one GPU; that was the packed-fp32 op_sel hazard of csrc/dev.h, which the
- *                        library no longer contains -- DESIGN.md section 8.)
- *   "gemm256_resid_prefetch"  1 (default): the fp32-residual epilogue of the 256x256 GEMM (o / down / fc2 / out projections at
- *                        batch-sized row counts) requests the 16 residual rows of a 64-row pass before staging the pass; 0: the
- *                        loads sit inside the store loop, four dependent round trips per pass (A/B).  Same arithmetic either way.
- *   "skinny_glu_2pass"   1 (default): a gate/up projection of the batched decode step that has more workgroups than the GPU has CUs
- *                        (hidden 2048: 384) stages each wave's K slice in two passes and keeps the partial tile of the cross-wave
- *                        reduction inside the wave's weight region, so that two workgroups fit on a CU; 0: one pass, one workgroup
- *                        per CU, a full round and a half-empty one.  Same arithmetic.  Taken at the next prefill.
- *   "dattn_pair_split"   0 / 1: when sequences x kv heads of a decode group would put a workgroup on at most half the CUs (16 sequences
- *                        x 8 kv heads on 256 CUs), the batched decode attention runs TWO workgroups per (sequence, kv head) on alternate
- *                        key tiles; the second to finish merges both partials inside the XCD's L2 (no waiting).  A merge that meets a
- *                        partner placed on another XCD is counted and turns the call into an error.  Taken at the next prefill.
  *   "skinny_glu_hp3"     1 (default): when the gate/up projection of the batched decode step has more 32-row pair tiles than the GPU has
  *                        CUs and its output columns divide into 3 half-pair tiles (8 gate + 8 up rows in one MFMA fragment) per
  *                        workgroup with at most one workgroup per CU (hidden 2048 / inter 6144: 256 workgroups), it runs in that
  *                        form: every CU streams the same number of weight bytes and the activations once; 0: never; 2: whenever
  *                        the shape allows (tests).  Same arithmetic.  Taken at the next prefill.
- *   "fattn_pipe"         0 / 1: the MFMA flash attention of batch-sized encoder windows / prefills as the software-pipelined kernel
- *                        (k_fattn.hip fattn_pipe_kernel: the softmax of key tile t issued between the QK MFMAs of tile t + 1, a ring
- *                        of four LDS stages) instead of fattn_dma_kernel; bit-identical results.  Read at every launch.
- *   "rope_variant"       hazard-isolation builds only (-DQ3A_ROPE_EXPERIMENT, never the product library): arithmetic form of
- *                        qknorm_rope_kv_kernel (csrc/dev.h head_norm_rope; tools/soak_engines.py).  Ignored by the product library.
- *   "rope_twice"         debug, 0 (default) / 1: batch-sized prefills execute the trailing rows' rope kernel a second time into
- *                        shadow buffers and compare (q3a_debug_read "rope_twice_log": 64 B of counters + 3584-byte records). */
+ * Round 6 removed the keys whose A/B is settled, together with the code only they selected (docs/HISTORY.md "Pruned in round 6"):
+ * fuse_qkv_attn, dattn_pair_split, fattn_pipe, rope_variant, rope_twice, gemm16_ring, gemm256_resid_prefetch, live_key_splits,
+ * skinny_glu_2pass.  An unknown key returns non-zero. */
 int32_t q3a_debug_set(const char* key, int32_t value);
 
 /* Kernel self-tests against naive device references (no model needed): returns max abs error. */

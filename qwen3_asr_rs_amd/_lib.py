@@ -15,12 +15,18 @@ SYMBOLS = [
     "q3a_engine_destroy", "q3a_last_error", "q3a_get_dims", "q3a_weights_rounded", "q3a_num_frames", "q3a_num_audio_tokens",
     "q3a_build_prompt", "q3a_mel", "q3a_encode", "q3a_prefill", "q3a_decode_step", "q3a_set_next_tokens",
     "q3a_upload_pcm", "q3a_run_resident", "q3a_fetch_ids", "q3a_transcribe_batch", "q3a_transcribe_batch_ptrs", "q3a_io_timings_last", "q3a_stage_timings",
-    "q3a_profile_decode_step", "q3a_profile_weight_stream", "q3a_debug_read", "q3a_debug_set", "q3a_selftest_gemm", "q3a_selftest_gemm16",
+    "q3a_profile_decode_step", "q3a_profile_weight_stream", "q3a_measure_peaks", "q3a_debug_read", "q3a_debug_set", "q3a_selftest_gemm", "q3a_selftest_gemm16",
     "q3a_load_audio", "q3a_resample", "q3a_resample_rubato", "q3a_free", "q3a_tokenizer_create", "q3a_tokenizer_destroy",
     "q3a_tokenizer_decode", "q3a_tokenizer_encode", "q3a_normalize_nfc", "q3a_parse_asr_output", "q3a_capitalize_first",
     "q3a_group_create", "q3a_group_destroy", "q3a_group_size", "q3a_group_used_rccl", "q3a_group_last_error",
     "q3a_group_engine", "q3a_group_partition", "q3a_group_transcribe", "q3a_group_transcribe_ptrs", "q3a_group_startup_seconds",
 ]
+
+
+class Peaks(C.Structure):
+    _fields_ = [("hbm_read_gbps", C.c_double), ("hbm_copy_gbps", C.c_double), ("hbm_triad_gbps", C.c_double), ("hbm_read_bytes", C.c_double),
+                ("mfma_bf16_tflops", C.c_double), ("gemm_m", C.c_int32), ("gemm_n", C.c_int32), ("gemm_k", C.c_int32), ("n_cu", C.c_int32),
+                ("reps", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Opts(C.Structure):
@@ -96,6 +102,7 @@ def load() -> C.CDLL:
         "q3a_stage_timings": (i32, [P, C.POINTER(Timings)]),
         "q3a_profile_decode_step": (i32, [P, C.POINTER(KernelProfile)]),
         "q3a_profile_weight_stream": (i32, [P, i32, f32p, C.POINTER(C.c_double), i32p]),
+        "q3a_measure_peaks": (i32, [i32, i32, C.POINTER(Peaks)]),
         "q3a_debug_read": (i32, [P, C.c_char_p, P, u64, C.POINTER(u64)]),
         "q3a_debug_set": (i32, [C.c_char_p, i32]),
         "q3a_selftest_gemm": (i32, [i32, i32, i32, i32, i32, f32p, f32p]),

@@ -167,7 +167,8 @@ __device__ __forceinline__ float lane_bcast(float v, int lane_uniform) {
 // modifier: the operand swap / high-register broadcast hipcc emits for scalar code it SLP-packs, or for {x, x} splats of the second
 // register of a 64-bit load) occasionally returns that half as if the product were 0, in lanes 48-63 only, while a second HIP queue
 // keeps the GPU busy -- reproduced with a hand-written instruction (the same multiply with the operands swapped in registers and
-// no op_sel never fails; tools/soak_engines.py + the Q3A_ROPE_EXPERIMENT variants below).  Consequences for this library:
+// no op_sel never fails; round 4's in-engine variants of head_norm_rope, removed in round 6 -- the standalone sweep
+// tools/pk_hazard.hip -> profiles/r5_pk_hazard.txt pins the failing set).  Consequences for this library:
 //   * it is built with -fno-slp-vectorize (qwen3_asr_rs_amd/build.py), so packed fp32 only comes from explicit f32x2_t code;
 //   * the build scans the ISA of every kernel and fails on any packed fp32 instruction with an op_sel bit set (build.py scan_isa);
 //   * no arithmetic in inline asm as a way around the packing: hipcc's hazard recogniser does not look inside asm blocks (a
@@ -189,45 +190,13 @@ __device__ __forceinline__ void rope_rotate(float n1, float n2, float c, float s
 
 // One wave per 128-wide head vector; the lane owns dims (lane, lane+64) = the rotate_half partners.
 // per-head RMSNorm (src/layers.rs:303-304,48-54) then RoPE (layers.rs:361-375)
-// VAR: 1 = product (plain scalar C++; with the SLP vectoriser off it stays scalar, and the build's ISA scan checks that).  -DQ3A_ROPE_EXPERIMENT builds (never the product library; knob `rope_variant`) add the forms that isolated the
-// hazard: 0 = plain C++ as hipcc SLP-packs it (v_pk_mul_f32 with crossed op_sel), 2 = 0 with idle cycles between the norm multiply
-// and the rotation, 3 = hand-written v_pk_mul_f32, operands swapped in registers, no op_sel, 4 = the swap done by op_sel:[0,1]
-// op_sel_hi:[0,0], 5 = 4 with a destination that overlaps no source.  Measured (32-clip prefills next to a second busy engine,
-// wrong vectors among 250 x 28 x 21504): 0: 232, 1: 0, 2: (31 events), 3: 0, 4: 211, 5: 309.
-template <int VAR = 1>
+// plain scalar C++; with the SLP vectoriser off it stays scalar, and the build's ISA scan checks that
 __device__ __forceinline__ void head_norm_rope(float& x1, float& x2, const float* __restrict__ w, float eps,
                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                int pos, int lane) {
   const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
   const float rstd = 1.0f / sqrtf(ss / 128.0f + eps);
   const float c = cos_t[(size_t)pos * 64 + lane], sn = sin_t[(size_t)pos * 64 + lane];
-#ifdef Q3A_ROPE_EXPERIMENT
-  if constexpr (VAR == 3 || VAR == 4 || VAR == 5) {
-    const float n1 = (x1 * rstd) * w[lane], n2 = (x2 * rstd) * w[lane + 64];
-    const f32x2_t N = {n1, n2}, C2 = {c, c}, S2 = {sn, sn};
-    f32x2_t A, Bv;
-    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(A) : "v"(N), "v"(C2));  // {n1 c, n2 c}
-    if constexpr (VAR == 3) {
-      float m1 = n1, m2 = n2;
-      asm volatile("" : "+v"(m1), "+v"(m2));
-      const f32x2_t Ns = {m2, m1};
-      asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(Bv) : "v"(Ns), "v"(S2));  // {n2 sn, n1 sn}
-    } else if constexpr (VAR == 4) {
-      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0]" : "=v"(Bv) : "v"(S2), "v"(N));  // {sn n2, sn n1}
-    } else {
-      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0]" : "=&v"(Bv) : "v"(S2), "v"(N));
-    }
-    x1 = A.x - Bv.x;
-    x2 = A.y + Bv.y;
-    return;
-  } else if constexpr (VAR == 0 || VAR == 2) {
-    float n1 = (x1 * rstd) * w[lane], n2 = (x2 * rstd) * w[lane + 64];
-    if constexpr (VAR == 2) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(n1), "+v"(n2));
-    x1 = n1 * c + (-n2) * sn;
-    x2 = n2 * c + n1 * sn;
-    return;
-  }
-#endif
   const float n1 = (x1 * rstd) * w[lane], n2 = (x2 * rstd) * w[lane + 64];
   rope_rotate(n1, n2, c, sn, x1, x2);
 }

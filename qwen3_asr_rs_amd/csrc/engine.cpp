@@ -110,17 +110,8 @@ Knobs& knobs() {
     env("Q3A_DECODE_PARALLEL", k.decode_parallel_groups);
     env("Q3A_FUSE_QKROPE", k.fuse_qkrope);
     env("Q3A_SKINNY_Q", k.skinny_q);
-    env("Q3A_FUSE_QKV_ATTN", k.fuse_qkv_attn);
     env("Q3A_EOS_RUN_AHEAD", k.eos_run_ahead);
-    env("Q3A_LIVE_KEY_SPLITS", k.live_key_splits);
-    env("Q3A_GEMM16_RING", k.gemm16_ring);
-    env("Q3A_GEMM256_RESID_PREFETCH", k.gemm256_resid_prefetch);
-    env("Q3A_FATTN_PIPE", k.fattn_pipe);
-    env("Q3A_SKINNY_GLU_2PASS", k.skinny_glu_2pass);
     env("Q3A_SKINNY_GLU_HP3", k.skinny_glu_hp3);
-    env("Q3A_DATTN_PAIR_SPLIT", k.dattn_pair_split);
-    env("Q3A_ROPE_VARIANT", k.rope_variant);
-    env("Q3A_DEBUG_ROPE_TWICE", k.rope_twice);
   });
   return k;
 }
@@ -161,15 +152,9 @@ struct q3a_engine {
   DevBuf x_dec, d_pos, next_tok, out_ids, step_count, done, s_ln, s_qkv, s_ctx, s_act, logits, forced_tok, part_val, part_idx;
   DevBuf attn_pm, attn_pl, attn_po;
   DevBuf nn_x, nn_ss;  // pre-normalised residual row for the next skinny GEMM: [32 * hidden] bf16 fragment order, [hidden/16][32] f32
-  DevBuf dbg_scratch;  // (debug) RopeKvArgs::dbg_scratch_copy
-  DevBuf dbg_k2, dbg_v2, dbg_q2, dbg_f1, dbg_f2, dbg_rope_log;  // (debug, knob rope_twice) shadow outputs of the re-executed rope kernel; [64 B counters | 64 x 3584 B records]
-  static constexpr int kRopeLogMax = 64;
   DevBuf rope_cur;  // [B][128] cos|sin row of each sequence's current position (kept by argmax_finalize for decode attention)
   DevBuf enc_ctx16, dec_ctx16;  // opts.valu_attention in the default mode: bf16 copy of the fp32 attention context
   DevBuf dec_q16;
-  DevBuf xcd_sync;  // arrival / departure words of the fused qkv + attention launch (one kv head per XCD)
-  DevBuf pair_sync; // pair-split batched decode attention (k_dattn.hip PAIR): [512 counters | 1024 XCC ids | error count], zeroed once
-  static constexpr int kPairCnt = 512, kPairXcc = 1024;
   int n_cu = 256;
   DevBuf n_done;    // device counter of sequences that have produced their EOS (argmax_finalize)
   int* host_prog = nullptr;      // pinned host words written by argmax_finalize (FinalizeArgs::host_progress), polled without a sync
@@ -182,7 +167,7 @@ struct q3a_engine {
   int gsize = 32;  // sequences per group of the batched decode step (<= 32: one skinny-GEMM weight sweep), fixed per batch
   // knobs that shape the decode step, latched per batch in setup_prompts: producers outside the captured graph (prefill
   // finalize, set_tokens) and the captured step must agree on them, and the graph signature names them
-  int k_parallel_groups = 1, k_skinny_q = 1, k_fuse_qkv_attn = 0, k_dattn_batched_min_wgs = 128, k_skinny_glu_2pass = 1, k_skinny_glu_hp3 = 1, k_dattn_pair_split = 0;
+  int k_parallel_groups = 1, k_skinny_q = 1, k_dattn_batched_min_wgs = 128, k_skinny_glu_hp3 = 1;
   std::vector<hipStream_t> chain_streams;
   std::vector<hipEvent_t> join_ev;
   hipEvent_t fork_ev = nullptr;
@@ -716,14 +701,10 @@ struct q3a_engine {
       const int gs = kn.decode_group_size.load();
       gsize = (gs >= 1 && gs <= 32) ? gs : 32;
       k_parallel_groups = kn.decode_parallel_groups.load(); k_skinny_q = kn.skinny_q.load();
-      k_fuse_qkv_attn = kn.fuse_qkv_attn.load(); k_dattn_batched_min_wgs = kn.dattn_batched_min_wgs.load();
-      k_skinny_glu_2pass = kn.skinny_glu_2pass.load();
+      k_dattn_batched_min_wgs = kn.dattn_batched_min_wgs.load();
       k_skinny_glu_hp3 = kn.skinny_glu_hp3.load();
-      k_dattn_pair_split = kn.dattn_pair_split.load();
     }
     const size_t ng = (size_t)n_groups(b);  // groups of <= gsize sequences of the batched decode step
-    if (!xcd_sync.p) { xcd_sync.ensure(2 * 8 * 64 * 4); HIPCHK(hipMemset(xcd_sync.p, 0, 2 * 8 * 64 * 4)); }  // (never inside a capture)
-    if (!pair_sync.p) { pair_sync.ensure((kPairCnt + kPairXcc + 16) * 4); HIPCHK(hipMemset(pair_sync.p, 0, (kPairCnt + kPairXcc + 16) * 4)); }
     nn_x.ensure(ng * 32 * H * 2); nn_ss.ensure((size_t)ng * (H / 8) * 32 * 4);  // room for the finer (8-column) partial rows whichever shape the knob selects later
     x_dec.ensure((size_t)b * H * 4); next_tok.ensure((size_t)b * 4); forced_tok.ensure((size_t)b * 4);
     out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
@@ -759,7 +740,7 @@ struct q3a_engine {
   // source for DevBuf members and fails when one is missing here.
   std::vector<DevBuf*> step_bufs() {
     return {&kcache, &vcache, &x_dec, &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits,
-            &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po, &nn_x, &nn_ss, &rope_cur, &rope_cos, &rope_sin, &xcd_sync, &pair_sync, &n_done, &forced_tok};
+            &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po, &nn_x, &nn_ss, &rope_cur, &rope_cos, &rope_sin, &n_done, &forced_tok};
   }
   std::vector<const DevBuf*> step_bufs() const {
     auto v = const_cast<q3a_engine*>(this)->step_bufs();
@@ -845,21 +826,7 @@ struct q3a_engine {
       rk.q16 = valu_attn ? nullptr : dec_q16.as<uint16_t>();
       if (fuse_rope) {
         // batch-sized prefill: QK-norm, RoPE and the cache append are the epilogue of the qkv GEMM (k_gemm256.hip)
-        const int M1 = gemm256_split_rows(total_P, QKV);
-        const bool twice = knobs().rope_twice.load() != 0 && M1 > 0;
-        if (twice) { dbg_f1.ensure((size_t)(total_P - M1) * QKV * 4); dbg_f2.ensure((size_t)(total_P - M1) * QKV * 4); rk.dbg_f32 = dbg_f1.as<float>(); }
         KCHK(launch_gemm256_qkrope(dec_ln.as<uint16_t>(), H, wh(l.qkv_w), total_P, H, qkv_bias ? wf(l.qkv_b) : nullptr, rk, stream));
-        if (twice) {
-          // (debug) the trailing rows' fp32 scratch is still intact: run the rope kernel on it again into shadow buffers and compare
-          dbg_k2.ensure(kv_layer_elems * 2); dbg_v2.ensure(kv_layer_elems * 2); dbg_q2.ensure((size_t)total_P * QD * 2);
-          if (!dbg_rope_log.p) { dbg_rope_log.ensure(64 + (size_t)kRopeLogMax * 3584); HIPCHK(hipMemsetAsync(dbg_rope_log.p, 0, dbg_rope_log.cap, stream)); }
-          RopeKvArgs r1 = rk;
-          r1.row_seq += M1; r1.row_pos += M1; r1.q16 += (size_t)M1 * d.n_q * 128;
-          RopeKvArgs r2 = r1;
-          r2.kcache = dbg_k2.p; r2.vcache = dbg_v2.p; r2.q16 = dbg_q2.as<uint16_t>() + (size_t)M1 * d.n_q * 128; r2.dbg_f32 = dbg_f2.as<float>();
-          KCHK(launch_qknorm_rope_kv(r2, total_P - M1, false, stream));
-          KCHK(launch_rope_compare(r1, r2, total_P - M1, li, dbg_rope_log.as<unsigned>(), (uint8_t*)dbg_rope_log.p + 64, kRopeLogMax, stream));
-        }
       } else {
         GemmEpilogue ep; ep.out = dec_qkv.as<float>(); ep.ldo = QKV; ep.bias = qkv_bias ? wf(l.qkv_b) : nullptr;
         act_gemm(dec_ln, H, wh(l.qkv_w), total_P, QKV, H, ep, false);
@@ -869,8 +836,6 @@ struct q3a_engine {
       // (debug_taps + Q3A_DEBUG_LAYER_TAPS=1: raw copies of every prefill layer's intermediate buffers, for bisecting a
       // run-to-run difference to one launch -- tools/bisect_layers.py)
       static const bool layer_taps = [] { const char* e = getenv("Q3A_DEBUG_LAYER_TAPS"); return e && atoi(e) != 0; }();
-      static const bool scratch_copy = [] { const char* e = getenv("Q3A_DEBUG_SCRATCH_COPY"); return e && atoi(e) != 0; }();
-      if (layer_taps && scratch_copy && opts.debug_taps) { dbg_scratch.ensure((size_t)1024 * QKV * 4); rk.dbg_scratch_copy = dbg_scratch.p; }
       auto ltap = [&](const char* what, const void* ptr, size_t bytes) {
         if (!layer_taps || !opts.debug_taps) return;
         char name[32];
@@ -880,7 +845,6 @@ struct q3a_engine {
       const size_t act_b = sp ? 4 : 2;  // bytes per activation element (bf16 in the default mode)
       if (fuse_rope) {
         ltap("qkvs", dec_qkv.p, std::min((size_t)1024, (size_t)total_P) * QKV * 4);  // fp32 scratch of the trailing rows (small GEMM -> separate rope kernel)
-        if (rk.dbg_scratch_copy) ltap("qkvm", rk.dbg_scratch_copy, std::min((size_t)1024, (size_t)total_P) * QKV * 4);  // the same, copied BETWEEN the two launches
       }
       ltap("k", kc_layer(li), (size_t)B * d.n_kv * max_ctx * 128 * kv_elem());
       ltap("v", vc_layer(li), (size_t)B * d.n_kv * max_ctx * 128 * kv_elem());
@@ -988,17 +952,8 @@ struct q3a_engine {
       g.fast_math = precise() ? 0 : 1;
       g.x = x; g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
       g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = qkv; g.ldo = QKV;
-      if (k_fuse_qkv_attn != 0 && S == 1 && d.n_kv == 8 && d.n_q == 16 && (H == 1024 || H == 2048) && live_nsplit_ <= 32) {
-        // one kv head per XCD: projection rows and key splits of a head share that XCD's L2 (k_dattn.hip qkv_attn_kernel)
-        QkvFuseArgs fa{};
-        fa.x = x; fa.rms_w = wf(l.in_ln); fa.eps = d.rms_eps; fa.W = wh(l.qkv_w); fa.bias = g.bias; fa.K = H;
-        fa.qkv_out = qkv; fa.sync = xcd_sync.as<unsigned>();
-        fa.debug = opts.debug_taps ? xcd_sync.as<unsigned>() + 8 * 64 : nullptr;
-        timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_qkv_attn(da, fa, kv_f32(), ks)); });
-      } else {
-        timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, ks)); });
-        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
-      }
+      timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, ks)); });
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
       GemvArgs o{};
       o.fast_math = precise() ? 0 : 1;
       if (std::min(S, 4) * d.n_q * live_nsplit_ <= GEMV_ATTN_MAX_TABLE) {  // merge the key splits inside the o_proj GEMV
@@ -1037,13 +992,6 @@ struct q3a_engine {
       // the group alone fills the chip: one workgroup per (sequence, kv head) walks all keys and writes the context itself
       if (b16) { da.out16 = reinterpret_cast<uint16_t*>(s_ctx_g(grp)); da.out_frag = 1; } else da.out = s_ctx_g(grp);
       da.trim_prologue = min_P_ < 2 * 128;  // some sequence is shorter than the kernel's two prologue key tiles
-      // at most half the CUs would get a workgroup (16 sequences x 8 kv heads on 256 CUs): two workgroups per (sequence, kv head)
-      if (k_dattn_pair_split != 0 && 2 * S * d.n_kv <= n_cu && d.n_kv == 8 && attn_nsplit >= 2 && (s0 + S) * d.n_kv <= kPairCnt) {
-        da.nsplit = attn_nsplit;
-        da.pair_cnt = pair_sync.as<unsigned>() + (size_t)s0 * d.n_kv;
-        da.pair_xcc = pair_sync.as<unsigned>() + kPairCnt + (size_t)s0 * d.n_kv * 2;
-        da.pair_err = pair_sync.as<unsigned>() + kPairCnt + kPairXcc;
-      }
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn_batched(da, S, kv_f32(), ks)); });
     } else {
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
@@ -1062,7 +1010,7 @@ struct q3a_engine {
     if (pre) { u.xw16f = nn_x_g(grp); u.ss_parts = nn_ss_g(grp); u.ss_nparts = nn_parts(); }
     else u.rms_w = wf(l.post_ln);
     u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act_g(grp); u.out16 = b16 ? reinterpret_cast<uint16_t*>(s_act_g(grp)) : nullptr; u.out16_frag = b16; u.ldo = I;
-    u.glu_1pass = k_skinny_glu_2pass == 0;
+    u.n_cu = n_cu;
     u.glu_hp3 = k_skinny_glu_hp3;
     timed(Q3A_KC_GEMM, 4.0 * I * H, [&] { KCHK(launch_skinny(u, precise(), ks)); });
     SkinnyArgs dn{};
@@ -1121,8 +1069,9 @@ struct q3a_engine {
       for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; }
     }
     char buf[256];
-    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d.%d.%d.%d/%d/%d/%p/%016llx", B, gsize, k_parallel_groups, k_skinny_q, k_fuse_qkv_attn,
-             k_dattn_batched_min_wgs, k_skinny_glu_2pass, k_skinny_glu_hp3 + 4 * k_dattn_pair_split + 8 * (min_P_ < 256), (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
+    // (one field per latched knob, as latched: packing several into one integer let distinct settings collide -- ADVICE r5)
+    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d.%d/%d/%d/%d/%p/%016llx", B, gsize, k_parallel_groups, k_skinny_q,
+             k_dattn_batched_min_wgs, k_skinny_glu_hp3, (int)(min_P_ < 256), (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
     return buf;
   }
 
@@ -1185,13 +1134,12 @@ struct q3a_engine {
     const int kps = dattn_keys_per_split(kv_f32());
     for (int i = 0; i < n; ++i) {
       // this step feeds the token at position <= pos_hi_ and attends keys 0 .. pos_hi_
-      live_nsplit_ = (uses_key_splits() && knobs().live_key_splits.load() != 0) ? std::min(attn_nsplit, pos_hi_ / kps + 1) : attn_nsplit;
+      live_nsplit_ = uses_key_splits() ? std::min(attn_nsplit, pos_hi_ / kps + 1) : attn_nsplit;
       if (eager) enqueue_decode_step();
       else HIPCHK(hipGraphLaunch(graph_for_step(), stream));
       ++pos_hi_;
     }
     if (eager) HIPCHK(hipGetLastError());
-    if (xcd_sync.p) tap("xcd_sync", xcd_sync.p, 2 * 8 * 64 * 4);  // (debug_taps only) counters + placement diagnostics of the fused launch
   }
 
   // steps 2-8 on the resident batch
@@ -1275,33 +1223,8 @@ struct q3a_engine {
     timings.decode_steps = steps; timings.batch = B; timings.total_audio_tokens = total_T; timings.total_prompt_tokens = total_P;
   }
 
-  // Fused qkv + attention launch (experimental knob): a wait on the in-XCD arrival counter that ran out means partial q/k/v
-  // entered the attention -- the ids are wrong, so every way out of the engine fails instead of returning them.
-  void check_fused_launch() {
-    if (k_dattn_pair_split && pair_sync.p) {  // pair-split attention: a merge that met a partial written on ANOTHER XCD read it through a different L2
-      unsigned bad = 0;
-      HIPCHK(hipMemcpy(&bad, pair_sync.as<unsigned>() + kPairCnt + kPairXcc, 4, hipMemcpyDeviceToHost));
-      if (bad) {
-        HIPCHK(hipMemset(pair_sync.p, 0, (kPairCnt + kPairXcc + 16) * 4));
-        fail("pair-split decode attention: " + std::to_string(bad) + " merge(s) met a partner on another XCD (workgroup placement is not id % 8); "
-             "the generated ids are invalid -- run with q3a_debug_set(\"dattn_pair_split\", 0)");
-      }
-    }
-    if (!k_fuse_qkv_attn || !xcd_sync.p) return;
-    unsigned w[8 * 64];
-    HIPCHK(hipMemcpy(w, xcd_sync.p, sizeof(w), hipMemcpyDeviceToHost));
-    unsigned n = 0;
-    for (int g = 0; g < 8; ++g) n += w[g * 64 + 48];
-    if (n) {
-      HIPCHK(hipMemset(xcd_sync.p, 0, 2 * 8 * 64 * 4));
-      fail("fused qkv + attention launch: " + std::to_string(n) + " in-XCD wait(s) ran out (workgroups of a kv head not co-located or "
-           "stalled); the generated ids are invalid -- run with q3a_debug_set(\"fuse_qkv_attn\", 0)");
-    }
-  }
-
   void fetch_ids(int32_t* out, int stride, int32_t* out_lens) {
     if (!have_prefill) fail("q3a_fetch_ids: nothing generated");
-    check_fused_launch();
     std::vector<int> all((size_t)B * max_new), sc(B);
     HIPCHK(hipMemcpy(all.data(), out_ids.p, all.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(sc.data(), step_count.p, (size_t)B * 4, hipMemcpyDeviceToHost));
@@ -1328,7 +1251,7 @@ struct q3a_engine {
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
                       &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
                       &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po,
-                      &enc_ctx16, &dec_ctx16, &dec_q16, &xcd_sync, &pair_sync, &zero_page, &rope_cur, &nn_x, &nn_ss, &n_done, &dbg_scratch, &dbg_k2, &dbg_v2, &dbg_q2, &dbg_f1, &dbg_f2, &dbg_rope_log};
+                      &enc_ctx16, &dec_ctx16, &dec_q16, &zero_page, &rope_cur, &nn_x, &nn_ss, &n_done};
     for (auto* b : bufs) b->release();
     for (auto& kv : taps) kv.second.release();
     if (own_arena && arena) (void)hipFree(arena);
@@ -1554,7 +1477,6 @@ int32_t q3a_decode_step(q3a_engine* e, int32_t* next_ids, uint8_t* done, float* 
   e->decode_steps(1);
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipGetLastError());
-  e->check_fused_launch();
   if (next_ids) HIPCHK(hipMemcpy(next_ids, e->next_tok.p, (size_t)e->B * 4, hipMemcpyDeviceToHost));
   if (done) HIPCHK(hipMemcpy(done, e->done.p, (size_t)e->B, hipMemcpyDeviceToHost));
   if (logits_out) HIPCHK(hipMemcpy(logits_out, e->logits.p, (size_t)e->B * e->d.vocab * 4, hipMemcpyDeviceToHost));
@@ -1614,8 +1536,9 @@ int32_t q3a_transcribe_batch_ptrs(q3a_engine* e, const float* const* pcm16k, con
   e->run_resident(fixed_new_tokens, true);
   e->fetch_ids(out_ids, stride, out_lens);
   if (e->io.mode != 0) {
+    // (a timing probe must not be able to fail the call: the marker sits on the copy stream, which fetch_ids did not synchronise)
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e->up_t0, e->up_t1));
+    if (hipEventSynchronize(e->up_t1) != hipSuccess || hipEventElapsedTime(&ms, e->up_t0, e->up_t1) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; }
     e->io.h2d_ms = ms;
   }
   e->io.wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - w0).count();
@@ -1744,16 +1667,6 @@ int32_t q3a_debug_read(q3a_engine* e, const char* name, void* dst, uint64_t byte
   if (!e) return 1;
   Q3A_TRY(e)
   HIPCHK(hipSetDevice(e->device));
-  if (strcmp(name, "rope_twice_log") == 0) {  // (debug, knob rope_twice) counters + mismatch records of launch_rope_compare
-    const size_t n = e->dbg_rope_log.cap;
-    if (actual) *actual = n;
-    if (dst && n) {
-      if (bytes < n) fail("q3a_debug_read: destination too small");
-      HIPCHK(hipStreamSynchronize(e->stream));
-      HIPCHK(hipMemcpy(dst, e->dbg_rope_log.p, n, hipMemcpyDeviceToHost));
-    }
-    return 0;
-  }
   auto it = e->taps.find(name);
   if (it == e->taps.end()) fail(std::string("q3a_debug_read: no tap named '") + name + "' (opts.debug_taps set?)");
   size_t n = e->tap_bytes[name];
@@ -1775,17 +1688,8 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   if (strcmp(key, "decode_parallel_groups") == 0) { kn.decode_parallel_groups = value; return 0; }
   if (strcmp(key, "fuse_qkrope") == 0) { kn.fuse_qkrope = value; return 0; }
   if (strcmp(key, "skinny_q") == 0) { kn.skinny_q = value; return 0; }
-  if (strcmp(key, "fuse_qkv_attn") == 0) { kn.fuse_qkv_attn = value; return 0; }
   if (strcmp(key, "eos_run_ahead") == 0) { kn.eos_run_ahead = value; return 0; }
-  if (strcmp(key, "live_key_splits") == 0) { kn.live_key_splits = value; return 0; }
-  if (strcmp(key, "gemm16_ring") == 0) { kn.gemm16_ring = value; return 0; }
-  if (strcmp(key, "gemm256_resid_prefetch") == 0) { kn.gemm256_resid_prefetch = value; return 0; }
-  if (strcmp(key, "fattn_pipe") == 0) { kn.fattn_pipe = value; return 0; }
-  if (strcmp(key, "skinny_glu_2pass") == 0) { kn.skinny_glu_2pass = value; return 0; }
   if (strcmp(key, "skinny_glu_hp3") == 0) { kn.skinny_glu_hp3 = value; return 0; }
-  if (strcmp(key, "dattn_pair_split") == 0) { kn.dattn_pair_split = value; return 0; }
-  if (strcmp(key, "rope_variant") == 0) { kn.rope_variant = value; return 0; }
-  if (strcmp(key, "rope_twice") == 0) { kn.rope_twice = value; return 0; }
   g_last_error = std::string("q3a_debug_set: unknown key '") + key + "'";
   return 1;
 }

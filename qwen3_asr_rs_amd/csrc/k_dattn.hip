@@ -52,15 +52,11 @@ template <> struct Frag16<float> {
 #endif
 constexpr int DA_WAVES = Q3A_DA_WAVES;  // waves per workgroup; a split is always 128 keys
 
-// Hooks of the fused qkv-projection + attention launch (qkv_attn_kernel below): `pre` runs before the cache rows are
-// requested (it requests the projection's weight rows: loads return in order, so those land first), `mid` after (it
-// finishes the projection, publishes the rows and waits for the other workgroups of the XCD); only then are the new token's
-// q/k/v rows read.  The plain kernel passes NoHook: the q/k/v rows are requested up front, in front of the cache rows.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-
-template <int GROUP, typename KVT, class Pre, class Mid>
-__device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const int kvh, const int s, const int sp, Pre pre, Mid mid) {
-  constexpr bool FUSED = !std::is_same<Mid, NoHook>::value;
+// (Round 2 built a fused qkv-projection + attention launch on top of this body -- qkv_attn_kernel, handed over inside each XCD --
+// and round 5 a pair-split form of the batched kernel below; both were correct and slower, and were removed in round 6:
+// docs/HISTORY.md, last present at commit caf7a05.)
+template <int GROUP, typename KVT>
+__device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const int kvh, const int s, const int sp) {
   constexpr int DPL = Frag16<KVT>::DPL;   // head dims per lane: 8 (bf16) / 4 (f32)
   constexpr int LPK = 128 / DPL;          // lanes per key: 16 / 32
   constexpr int KPI = 64 / LPK;           // keys per load instruction: 4 / 2
@@ -103,15 +99,14 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
       x2 = row[r * 128 + lane + 64];
     }
   };
-  if (wave <= GROUP) {  // (independent of the projection: requested up front in both forms)
+  if (wave <= GROUP) {
     const float* nw = wave < GROUP ? a.q_norm : a.k_norm;
     nw1 = nw[lane];
     nw2 = nw[lane + 64];
     c = a.rope_cur[(size_t)s * 128 + lane];
     sn = a.rope_cur[(size_t)s * 128 + 64 + lane];
   }
-  if constexpr (!FUSED) load_rows();
-  pre();
+  load_rows();
   // 2. the cache rows, unconditionally (rows at or beyond pos hold stale data and are masked below; the index is
   //    clamped to the allocation)
   const int key_base = key_lo + wave * KEYS_PER_WAVE + kq;
@@ -126,10 +121,6 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     kraw[i] = *reinterpret_cast<const uint4*>(kc + (size_t)key * 128 + sub * DPL);
     vraw[i] = *reinterpret_cast<const uint4*>(vc + (size_t)key * 128 + sub * DPL);
 #endif
-  }
-  if constexpr (FUSED) {
-    mid();
-    load_rows();
   }
   __builtin_amdgcn_sched_barrier(0);
   Q3A_STAMP_AT(a.stamp, stamp_wg, 1);  // every load requested
@@ -269,135 +260,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
 
 template <int GROUP, typename KVT>
 __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnArgs a) {
-  decode_attn_body<GROUP, KVT>(a, blockIdx.x, blockIdx.y, blockIdx.z, NoHook{}, NoHook{});
-}
-
-// ---- one sequence: qkv projection + attention in ONE launch ---------------------------------------------------------------
-// kv head g needs exactly the rows q[GROUP*g .. GROUP*g+GROUP), k[g], v[g] of the projection: (GROUP + 2) * 128 = 512 rows at
-// GROUP = 2.  With 8 kv heads and 256 workgroups, workgroup b works for kv head g = b % 8 -- the 32 workgroups the dispatcher
-// places on XCD g -- and computes 16 of those rows (8 waves x 2 rows, the arithmetic of gemv1_kernel<2, KI, true, false>);
-// workgroups 0 .. nsplit-1 of the XCD are also the key splits of the attention.  The hand-off stays inside the XCD: rows
-// are stored (write-through to that XCD's L2, acknowledged by vmcnt), a counter in the same L2 is bumped with a
-// workgroup-scope RMW, and the split workgroups spin on it: 0.3 us for the barrier + 0.4 us for a 2 KiB hand-off against
-// 1.55 us for a kernel boundary and 3.9 us for the same barrier at agent scope (profiles/r2_cluster_barrier.txt).  The
-// splits request their cache rows BEFORE they wait, so the KV round trip hides behind the projection.  The spin is bounded
-// (a lost arrival would produce a wrong token, never a hung box); the last split to leave re-arms the counters.
-struct QkvFuse {
-  const float* x; const float* rms_w; float eps;   // [K] hidden row of the token, input-norm weight
-  const uint16_t* W; const float* bias; int K;     // [(n_q + 2 n_kv) * 128][K]
-  float* qkv_out;                                   // = DecodeAttnArgs::qkv
-  unsigned* sync;                                   // [8][64] words: [g][0] arrivals, [g][32] departures, [g][48] STICKY count of
-                                                    // waits that ran out (never cleared by the kernel: the host fails on it)
-  unsigned* debug;                                  // optional [8][64]: [g][slot] = XCC_ID the workgroup ran on, [g][32] = waits that
-                                                    // ran out, [g][33 + split] = arrivals seen when they did
-};
-
-__device__ __forceinline__ float qa_dot8(const uint4& w, const float (&x)[8], float s) {  // (k_gemv.hip dot8)
-  f32x2_t a = f32x2_t{bf16lo(w.x), bf16hi(w.x)} * f32x2_t{x[0], x[1]};
-  a += f32x2_t{bf16lo(w.y), bf16hi(w.y)} * f32x2_t{x[2], x[3]};
-  a += f32x2_t{bf16lo(w.z), bf16hi(w.z)} * f32x2_t{x[4], x[5]};
-  a += f32x2_t{bf16lo(w.w), bf16hi(w.w)} * f32x2_t{x[6], x[7]};
-  return s + (a.x + a.y);
-}
-
-template <int GROUP, int KI>
-struct QkvRows {  // the two projection rows of one wave: request(), then finish()
-  float4 xr[KI][2], nr[KI][2];
-  uint4 wq[KI][2];
-  int row[2];
-  __device__ __forceinline__ void request(const QkvFuse& f, int g, int slot, int n_q, int n_kv) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = slot * 16 + wave * 2 + i;  // row inside the kv head's (GROUP + 2) * 128
-      row[i] = r < GROUP * 128 ? g * GROUP * 128 + r
-             : r < GROUP * 128 + 128 ? n_q * 128 + g * 128 + (r - GROUP * 128)
-                                     : (n_q + n_kv) * 128 + g * 128 + (r - GROUP * 128 - 128);
-    }
-#pragma unroll
-    for (int it = 0; it < KI; ++it) {
-      const int k = lane * 8 + it * 512;
-      xr[it][0] = *reinterpret_cast<const float4*>(f.x + k);
-      xr[it][1] = *reinterpret_cast<const float4*>(f.x + k + 4);
-      nr[it][0] = *reinterpret_cast<const float4*>(f.rms_w + k);
-      nr[it][1] = *reinterpret_cast<const float4*>(f.rms_w + k + 4);
-    }
-#pragma unroll
-    for (int it = 0; it < KI; ++it)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) wq[it][i] = ld_stream16(f.W + (size_t)row[i] * f.K + lane * 8 + it * 512);
-  }
-  __device__ __forceinline__ void finish(const QkvFuse& f) {
-    const int lane = threadIdx.x & 63;
-    float x[KI][8];
-    float ss = 0.f;
-#pragma unroll
-    for (int it = 0; it < KI; ++it) {
-      const float4 v0 = xr[it][0], v1 = xr[it][1], w0 = nr[it][0], w1 = nr[it][1];
-      const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { ss += xv[e] * xv[e]; x[it][e] = xv[e] * wv[e]; }
-    }
-    float acc[2] = {0.f, 0.f};
-#pragma unroll
-    for (int it = 0; it < KI; ++it)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = qa_dot8(wq[it][i], x[it], acc[i]);
-    const float rstd = 1.0f / sqrtf(wave_sum_fast(ss) / (float)f.K + f.eps);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float y = wave_sum_fast(acc[i]) * rstd + (f.bias ? f.bias[row[i]] : 0.f);
-      if (lane == 0) f.qkv_out[row[i]] = y;
-    }
-  }
-};
-
-// every wave has stored its rows: make them visible in the XCD's L2 and count this workgroup in
-__device__ __forceinline__ void xcd_arrive(unsigned* cnt) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a store is acknowledged when the L2 has it
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // RMW: executed in the L2
-}
-__device__ __forceinline__ void xcd_wait(unsigned* cnt, unsigned members, unsigned waiters, unsigned* dbg, int slot) {
-  if (threadIdx.x == 0) {
-    int spins = 0;
-    unsigned seen = 0;
-    // The poll is an AGENT-scope load (sc1: served by the L2, past this CU's L1).  A workgroup-scope fetch_add(p, 0) is folded
-    // by the compiler into a workgroup-scope load (sc0), which keeps hitting the L1 line of the first poll: measured as
-    // waits that ran out at 29..31 of 32 arrivals in every second launch.
-    while ((seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < members && ++spins < (1 << 16))
-      __builtin_amdgcn_s_sleep(1);
-    if (seen < members) {  // the wait ran out (placement not one kv head per XCD, or a stalled peer): the result is invalid
-      atomicAdd(cnt + 48, 1u);
-      if (dbg) { atomicAdd(dbg + 32, 1u); dbg[33 + slot] = seen; }
-    }
-    if (__hip_atomic_fetch_add(cnt + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == waiters - 1) {  // last one out
-      __hip_atomic_exchange(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_exchange(cnt + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-  }
-  __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop this CU's L1 lines of the qkv row (last layer's values)
-}
-
-template <int GROUP, typename KVT, int KI>
-__global__ __launch_bounds__(DA_WAVES * 64) void qkv_attn_kernel(DecodeAttnArgs a, QkvFuse f) {
-  static_assert(DA_WAVES == 8, "16 projection rows per workgroup = 8 waves x 2");
-  const int g = blockIdx.x & 7, slot = blockIdx.x >> 3;  // kv head = XCD, member of its 32 workgroups
-  unsigned* const cnt = f.sync + g * 64;
-  unsigned* const dbg = f.debug ? f.debug + g * 64 : nullptr;
-  if (dbg && threadIdx.x == 0) dbg[slot] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) + 1u;  // HW_REG_XCC_ID[3:0] + 1
-  QkvRows<GROUP, KI> rows;
-  if (slot >= a.nsplit) {  // projection only
-    rows.request(f, g, slot, a.n_q, a.n_kv);
-    rows.finish(f);
-    xcd_arrive(cnt);
-    return;
-  }
-  decode_attn_body<GROUP, KVT>(a, g, 0, slot,
-      [&]() { rows.request(f, g, slot, a.n_q, a.n_kv); },
-      [&]() { rows.finish(f); xcd_arrive(cnt); xcd_wait(cnt, 32u, (unsigned)a.nsplit, dbg, slot); });
+  decode_attn_body<GROUP, KVT>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 
@@ -415,16 +278,7 @@ template <bool B> struct BoolC { static constexpr bool value = B; };  // compile
 #ifndef Q3A_DATTN_RING
 #define Q3A_DATTN_RING 2  // tiles in flight per wave (A/B: 2 = one tile ahead 15.3 us per layer at 32 x 500 keys, 3 = 16.6 us)
 #endif
-// PAIR (round 5): grid (kv head, sequence, 2).  With 16 sequences x 8 kv heads only 128 of 256 CUs had a workgroup; now workgroup
-// z of a (sequence, kv head) walks the key tiles t = z, z + 2, ... and the two are merged by whichever finishes second: each stores
-// its unnormalised (m, l, o) to pm / pl / po, waits for the stores to reach the L2, and counts itself in with an L2-resolved RMW; the
-// one that reads 1 takes the partner's partial, merges, normalises, writes the context and returns the counter to 0.  No waiting,
-// so no deadlock by construction.  Both workgroups of a pair have blockIdx.x = kv head and the dispatcher places workgroup i on XCD
-// i % 8 (linear id = x + 8 (y + S z), x < 8), so they share an L2 and the hand-off needs no L2 write-back (HISTORY 3.2: 0.3 us
-// inside an XCD, 3-4 us across); each partial carries its XCC_ID and a merge that meets another XCD's counts an error the engine
-// turns into a failure (never a silent wrong context).  The tile that holds position `pos` belongs to one of the two: that one
-// appends the new k / v rows.
-template <int GROUP, typename KVT, int TILE = 128, int RING_T = Q3A_DATTN_RING, bool PAIR = false>
+template <int GROUP, typename KVT, int TILE = 128, int RING_T = Q3A_DATTN_RING>
 __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(DecodeAttnArgs a) {
   constexpr int DPL = Frag16<KVT>::DPL;
   constexpr int LPK = 128 / DPL;
@@ -442,10 +296,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   // of the first cache-row request
   Q3A_ARG(a.qkv); Q3A_ARG(a.pos); Q3A_ARG(a.q_norm); Q3A_ARG(a.k_norm); Q3A_ARG(a.eps); Q3A_ARG(a.rope_cur); Q3A_ARG(a.kcache); Q3A_ARG(a.vcache);
   Q3A_ARG(a.n_q); Q3A_ARG(a.n_kv); Q3A_ARG(a.max_ctx); Q3A_ARG(a.scale_div); Q3A_ARG(a.out); Q3A_ARG(a.out16); Q3A_ARG(a.out_frag); Q3A_ARG(a.trim_prologue);
-  if (PAIR) { Q3A_ARG(a.pm); Q3A_ARG(a.pl); Q3A_ARG(a.po); Q3A_ARG(a.pair_cnt); Q3A_ARG(a.pair_xcc); Q3A_ARG(a.pair_err); }
   const int kvh = blockIdx.x, s = blockIdx.y;
-  const int zh = PAIR ? (int)blockIdx.z : 0;   // which half of the key tiles
-  constexpr int TSTEP = PAIR ? 2 : 1;          // my j-th tile is tile zh + TSTEP * j
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int stamp_wg = blockIdx.y * gridDim.x + blockIdx.x;
   Q3A_STAMP_AT(a.stamp, stamp_wg, 0);  // entry
@@ -472,7 +323,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   // HBM (they are masked either way).  The last tile of a context is half empty on average: 11 % of the bytes at 405-505 keys
   // (PMC: 68.2 MB fetched per launch for 59.6 MB of live rows).
   auto load_tile = [&](int j, uint4 (&kr)[NI], uint4 (&vr)[NI], const bool trim = false, const int pos_row = 0) {
-    const int t = zh + TSTEP * j;
+    const int t = j;
     if (!trim) {
       const size_t base = (size_t)min(t, last_tile) * (TILE * 128) + lane_off;
 #pragma unroll
@@ -524,9 +375,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   if constexpr (RING > 3) load_tile(3, kr3, vr3, TRIM_PRO, pos);
   __builtin_amdgcn_sched_barrier(0);
   Q3A_STAMP_AT(a.stamp, stamp_wg, 1);  // q/k/v row + first tiles requested
-  const int n_all = pos / TILE + 1;  // tiles that hold at least one key <= pos
-  const int n_tiles = PAIR ? (n_all - zh + 1) / 2 : n_all;  // ... of which mine (PAIR: may be 0 for the odd half of a short context)
-  const bool own_pos = !PAIR || (((pos / TILE) & 1) == zh);  // my tiles include the one that receives the new token's k / v rows
+  const int n_tiles = pos / TILE + 1;  // tiles that hold at least one key <= pos
 
   if (wave <= GROUP) {  // per-head RMSNorm + RoPE (as dev.h head_norm_rope)
     const float ss = wave_sum_fast(x1 * x1 + x2 * x2);
@@ -538,17 +387,13 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
     q_s[wave][lane] = x1;
     q_s[wave][lane + 64] = x2;
   } else if (wave == GROUP) {
-    if (own_pos) {
-      KvIo<KVT>::store(kc + (size_t)pos * 128 + lane, x1);
-      KvIo<KVT>::store(kc + (size_t)pos * 128 + lane + 64, x2);
-    }
+    KvIo<KVT>::store(kc + (size_t)pos * 128 + lane, x1);
+    KvIo<KVT>::store(kc + (size_t)pos * 128 + lane + 64, x2);
     KvIo<KVT>::store(&k_s[lane], x1);
     KvIo<KVT>::store(&k_s[lane + 64], x2);
   } else if (wave == GROUP + 1) {
-    if (own_pos) {
-      KvIo<KVT>::store(vc + (size_t)pos * 128 + lane, x1);
-      KvIo<KVT>::store(vc + (size_t)pos * 128 + lane + 64, x2);
-    }
+    KvIo<KVT>::store(vc + (size_t)pos * 128 + lane, x1);
+    KvIo<KVT>::store(vc + (size_t)pos * 128 + lane + 64, x2);
     KvIo<KVT>::store(&v_s[lane], x1);
     KvIo<KVT>::store(&v_s[lane + 64], x2);
   }
@@ -584,7 +429,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   // and the tile index are SGPRs), the arithmetic of an inner tile is the same instruction for instruction: bit-identical.
   auto tile_body = [&](auto edge_c, int j, const uint4 (&kraw)[NI], const uint4 (&vraw)[NI]) {
     constexpr bool EDGE = decltype(edge_c)::value;
-    const int key_base = (zh + TSTEP * j) * TILE + key_w;
+    const int key_base = j * TILE + key_w;
     float sc[NI][GROUP];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -646,11 +491,11 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
 #endif
   const int edge_tile = pos / TILE;  // the tile that holds position `pos`: the last one with a live key
   auto consume = [&](int j, const uint4 (&kraw)[NI], const uint4 (&vraw)[NI]) {
-    if (Q3A_DATTN_EDGE && zh + TSTEP * j < edge_tile) {
+    if (Q3A_DATTN_EDGE && j < edge_tile) {
       tile_body(BoolC<false>{}, j, kraw, vraw);
       return;
     }
-    const int key_base = (zh + TSTEP * j) * TILE + key_w;
+    const int key_base = j * TILE + key_w;
     uint4 kp[NI], vp[NI];  // the tile with the new token's rows patched in and the rows past it blanked
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -709,52 +554,13 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(Deco
   if (wave < GROUP) {
     const int g = wave;
 #pragma unroll
-    for (int w = 0; w < DA_WAVES; ++w) M = fmaxf(M, cm[w][g]);  // finite unless PAIR and none of my tiles is live (key 0 <= pos always exists)
+    for (int w = 0; w < DA_WAVES; ++w) M = fmaxf(M, cm[w][g]);  // finite: key 0 <= pos always exists
 #pragma unroll
     for (int w = 0; w < DA_WAVES; ++w) {
       const float f = (cm[w][g] == -INFINITY) ? 0.f : expw(cm[w][g] - M);
       L += cl[w][g] * f;
       o0 += co[w][g][lane] * f;
       o1 += co[w][g][lane + 64] * f;
-    }
-  }
-  if constexpr (PAIR) {
-    __shared__ unsigned pair_old;
-    const unsigned my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));  // HW_REG_XCC_ID[3:0]
-    const size_t slot = ((size_t)s * a.n_q + (size_t)kvh * GROUP);                          // + g, then * 2 + half
-    if (wave < GROUP) {
-      const size_t mine = (slot + wave) * 2 + zh;
-      a.po[mine * 128 + lane] = o0;
-      a.po[mine * 128 + lane + 64] = o1;
-      if (lane == 0) { a.pm[mine] = M; a.pl[mine] = L; }
-    }
-    if (tid == 64 * GROUP) a.pair_xcc[((size_t)s * a.n_kv + kvh) * 2 + zh] = my_xcc;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a store is acknowledged when the L2 has it
-    __syncthreads();
-    if (tid == 0) pair_old = __hip_atomic_fetch_add(a.pair_cnt + (size_t)s * a.n_kv + kvh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // RMW: executed in the L2
-    __syncthreads();
-    if (pair_old == 0) return;  // the partner finishes second and merges
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing of the partner's partial may come from this CU's L1
-    if (tid == 0) {
-      __hip_atomic_exchange(a.pair_cnt + (size_t)s * a.n_kv + kvh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ready for the next launch
-      const unsigned other_xcc = __hip_atomic_load(a.pair_xcc + ((size_t)s * a.n_kv + kvh) * 2 + (zh ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (other_xcc != my_xcc) atomicAdd(a.pair_err, 1u);
-    }
-    if (wave < GROUP) {
-      const size_t other = (slot + wave) * 2 + (zh ^ 1);
-      const float M2 = __hip_atomic_load(a.pm + other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float L2 = __hip_atomic_load(a.pl + other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float p0 = __hip_atomic_load(a.po + other * 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const float p1 = __hip_atomic_load(a.po + other * 128 + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // merge in tile order (even half first) so that the result does not depend on which workgroup arrived second
-      const bool me_first = zh == 0;
-      const float Ma = me_first ? M : M2, Mb = me_first ? M2 : M, La = me_first ? L : L2, Lb = me_first ? L2 : L;
-      const float a0 = me_first ? o0 : p0, b0 = me_first ? p0 : o0, a1 = me_first ? o1 : p1, b1 = me_first ? p1 : o1;
-      const float Mt = fmaxf(Ma, Mb);
-      const float fa = (Ma == -INFINITY) ? 0.f : expw(Ma - Mt), fb = (Mb == -INFINITY) ? 0.f : expw(Mb - Mt);
-      L = La * fa + Lb * fb;
-      o0 = a0 * fa + b0 * fb;
-      o1 = a1 * fa + b1 * fb;
     }
   }
   if (wave < GROUP) {
@@ -825,24 +631,6 @@ const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipS
   return nullptr;
 }
 
-const char* launch_qkv_attn(const DecodeAttnArgs& a, const QkvFuseArgs& fa, bool kv_f32, hipStream_t s) {
-  const int group = a.n_q / a.n_kv;
-  if (a.n_kv != 8 || group != 2) return "qkv_attn: 8 kv heads with 2 query heads each (one kv head per XCD)";
-  if (fa.K != 1024 && fa.K != 2048) return "qkv_attn: hidden size 1024 or 2048";
-  if (a.nsplit <= 0 || a.nsplit > 32 || (a.nsplit - 1) * dattn_keys_per_split(kv_f32) >= a.max_ctx) return "qkv_attn: 1..32 key splits inside max_ctx";
-  if (!fa.sync || !fa.rms_w || fa.qkv_out != a.qkv) return "qkv_attn: sync words, norm weight and the shared qkv row are required";
-  QkvFuse f{fa.x, fa.rms_w, fa.eps, fa.W, fa.bias, fa.K, fa.qkv_out, fa.sync, fa.debug};
-  const dim3 grid(256), block(DA_WAVES * 64);
-  if (fa.K == 1024) {
-    if (kv_f32) hipLaunchKernelGGL((qkv_attn_kernel<2, float, 2>), grid, block, 0, s, a, f);
-    else hipLaunchKernelGGL((qkv_attn_kernel<2, uint16_t, 2>), grid, block, 0, s, a, f);
-  } else {
-    if (kv_f32) hipLaunchKernelGGL((qkv_attn_kernel<2, float, 4>), grid, block, 0, s, a, f);
-    else hipLaunchKernelGGL((qkv_attn_kernel<2, uint16_t, 4>), grid, block, 0, s, a, f);
-  }
-  return nullptr;
-}
-
 // (S * n_kv -- the workgroups of the batched kernel -- from which the engine's batched decode step uses it is the knob
 // dattn_batched_min_wgs of kernels.h; below it the key-split kernel + merge keep more CUs busy.)
 
@@ -853,21 +641,6 @@ const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f
   if (a.max_ctx % 128 != 0) return "decode_attn_batched: max_ctx must be a multiple of 128 (whole key tiles)";
   const int group = a.n_q / a.n_kv;
   dim3 grid(a.n_kv, S), block(DA_WAVES * 64);
-  if (a.pair_cnt) {  // two workgroups per (sequence, kv head), merged inside the XCD (engine: 2 S n_kv <= CUs, 8 kv heads)
-    if (a.n_kv != 8 || a.nsplit < 2 || !a.pm || !a.pl || !a.po || !a.pair_xcc || !a.pair_err) return "decode_attn_batched: pair split needs 8 kv heads, two partial slots per head and its sync words";
-    const dim3 grid2(a.n_kv, S, 2);
-#define Q3A_DAP(G)                                                                                                                        \
-  do {                                                                                                                                    \
-    if (kv_f32) hipLaunchKernelGGL((decode_attn_batched_kernel<G, float, 128, 1, true>), grid2, block, 0, s, a);                          \
-    else hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t, 128, Q3A_DATTN_RING, true>), grid2, block, 0, s, a);                 \
-  } while (0)
-    if (group == 1) Q3A_DAP(1);
-    else if (group == 2) Q3A_DAP(2);
-    else if (group == 4) Q3A_DAP(4);
-    else return "decode_attn_batched: GQA group must be 1, 2 or 4";
-#undef Q3A_DAP
-    return nullptr;
-  }
   // (Round 5 measured two more shapes of the ring here -- 64-key tiles x 4 in flight, 128-key tiles x 4 in flight -- behind
   // environment switches; both lost at 16 and 32 sequences (profiles/r5_ab_dattn_ring_16seq.txt) and their instantiations are gone:
   // the template still takes TILE and RING_T.)

@@ -77,7 +77,7 @@ __global__ void set_tokens_kernel(const int* __restrict__ tok, const uint16_t* _
   embed_row(embed, id, H, x_next, s, nn, red);
 }
 
-template <typename KVT, int VAR>
+template <typename KVT>
 __global__ __launch_bounds__(256) void qknorm_rope_kv_kernel(RopeKvArgs a, int rows) {
   const int lane = threadIdx.x & 63;
   const int nvec = a.n_q + 2 * a.n_kv;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kv_kernel(RopeKvArgs a, int r
   float x1 = base[lane], x2 = base[lane + 64];
   const int pos = a.row_pos[row], seq = a.row_seq[row];
   if (hv < a.n_q) {
-    head_norm_rope<VAR>(x1, x2, a.q_norm, a.eps, a.cos_t, a.sin_t, pos, lane);
+    head_norm_rope(x1, x2, a.q_norm, a.eps, a.cos_t, a.sin_t, pos, lane);
     if (a.q16) {
       uint16_t* q = a.q16 + (size_t)row * a.n_q * 128 + (size_t)hv * 128;
       q[lane] = (uint16_t)f32_to_bf16_bits(x1);
@@ -100,64 +100,10 @@ __global__ __launch_bounds__(256) void qknorm_rope_kv_kernel(RopeKvArgs a, int r
   } else {
     const bool is_k = hv < a.n_q + a.n_kv;
     const int kvh = is_k ? hv - a.n_q : hv - a.n_q - a.n_kv;
-    if (is_k) head_norm_rope<VAR>(x1, x2, a.k_norm, a.eps, a.cos_t, a.sin_t, pos, lane);
+    if (is_k) head_norm_rope(x1, x2, a.k_norm, a.eps, a.cos_t, a.sin_t, pos, lane);
     KVT* c = reinterpret_cast<KVT*>(is_k ? a.kcache : a.vcache) + (((size_t)seq * a.n_kv + kvh) * a.max_ctx + pos) * 128;
     KvIo<KVT>::store(c + lane, x1);
     KvIo<KVT>::store(c + lane + 64, x2);
-  }
-  if (a.dbg_f32) {  // (debug, knob rope_twice)
-    a.dbg_f32[(size_t)vi * 128 + lane] = x1;
-    a.dbg_f32[(size_t)vi * 128 + lane + 64] = x2;
-  }
-}
-
-// (debug, knob rope_twice) The rope kernel ran twice on the same scratch: once into the real q / KV cache, once into shadow
-// buffers.  One wave per head vector compares the two results bit for bit; a mismatch takes a log slot and dumps both results
-// and every input of that vector (transient execution error or data?).
-__global__ __launch_bounds__(256) void rope_compare_kernel(RopeKvArgs a, RopeKvArgs b, int rows, int layer, unsigned* counters,
-                                                           unsigned char* log, int max_log) {
-  const int lane = threadIdx.x & 63;
-  const int nvec = a.n_q + 2 * a.n_kv;
-  const long vi = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (vi >= (long)rows * nvec) return;
-  const int row = (int)(vi / nvec), hv = (int)(vi % nvec);
-  const int pos = a.row_pos[row], seq = a.row_seq[row];
-  const uint16_t *pa, *pb;
-  const float* w = nullptr;
-  if (hv < a.n_q) {
-    pa = a.q16 + (size_t)row * a.n_q * 128 + (size_t)hv * 128;
-    pb = b.q16 + (size_t)row * a.n_q * 128 + (size_t)hv * 128;
-    w = a.q_norm;
-  } else {
-    const bool is_k = hv < a.n_q + a.n_kv;
-    const int kvh = is_k ? hv - a.n_q : hv - a.n_q - a.n_kv;
-    const size_t off = (((size_t)seq * a.n_kv + kvh) * a.max_ctx + pos) * 128;
-    pa = reinterpret_cast<const uint16_t*>(is_k ? a.kcache : a.vcache) + off;
-    pb = reinterpret_cast<const uint16_t*>(is_k ? b.kcache : b.vcache) + off;
-    if (is_k) w = a.k_norm;
-  }
-  const uint16_t a1 = pa[lane], a2 = pa[lane + 64], b1 = pb[lane], b2 = pb[lane + 64];
-  const bool bad = a1 != b1 || a2 != b2;
-  if (__ballot(bad) == 0) return;
-  unsigned slot = 0;
-  if (lane == 0) slot = atomicAdd(counters + 1, 1u);
-  slot = __builtin_amdgcn_readfirstlane(slot);
-  if ((int)slot >= max_log) return;
-  unsigned char* e = log + (size_t)slot * 3584;
-  int* hdr = reinterpret_cast<int*>(e);
-  if (lane == 0) { hdr[0] = layer; hdr[1] = row; hdr[2] = hv; hdr[3] = pos; hdr[4] = seq; hdr[5] = w ? 1 : 0; hdr[6] = 0; hdr[7] = 0; }
-  uint16_t* ra = reinterpret_cast<uint16_t*>(e + 32);
-  uint16_t* rb = ra + 128;
-  ra[lane] = a1; ra[lane + 64] = a2; rb[lane] = b1; rb[lane + 64] = b2;
-  float* f = reinterpret_cast<float*>(e + 32 + 512);
-  const float* x = a.qkv + (size_t)row * nvec * 128 + (size_t)hv * 128;
-  f[lane] = x[lane]; f[lane + 64] = x[lane + 64];
-  f[128 + lane] = w ? w[lane] : 0.f; f[192 + lane] = w ? w[lane + 64] : 0.f;
-  f[256 + lane] = a.cos_t[(size_t)pos * 64 + lane];
-  f[320 + lane] = a.sin_t[(size_t)pos * 64 + lane];
-  if (a.dbg_f32 && b.dbg_f32) {
-    f[384 + lane] = a.dbg_f32[(size_t)vi * 128 + lane]; f[448 + lane] = a.dbg_f32[(size_t)vi * 128 + lane + 64];
-    f[512 + lane] = b.dbg_f32[(size_t)vi * 128 + lane]; f[576 + lane] = b.dbg_f32[(size_t)vi * 128 + lane + 64];
   }
 }
 
@@ -266,25 +212,10 @@ const char* launch_qknorm_rope_kv(const RopeKvArgs& a, int rows, bool kv_f32, hi
   if (rows <= 0) return nullptr;
   const long nvec = (long)rows * (a.n_q + 2 * a.n_kv);
   const int blocks = (int)((nvec + 3) / 4);
-#ifdef Q3A_ROPE_EXPERIMENT  // (hazard isolation builds: dev.h head_norm_rope)
-  const int var = knobs().rope_variant.load(std::memory_order_relaxed);
-#define Q3A_ROPE_CASE(V) if (!kv_f32 && var == V) { hipLaunchKernelGGL((qknorm_rope_kv_kernel<uint16_t, V>), dim3(blocks), dim3(256), 0, s, a, rows); return nullptr; }
-  Q3A_ROPE_CASE(0) Q3A_ROPE_CASE(2) Q3A_ROPE_CASE(3) Q3A_ROPE_CASE(4) Q3A_ROPE_CASE(5)
-#undef Q3A_ROPE_CASE
-#endif
-  if (kv_f32) hipLaunchKernelGGL((qknorm_rope_kv_kernel<float, 1>), dim3(blocks), dim3(256), 0, s, a, rows);
-  else hipLaunchKernelGGL((qknorm_rope_kv_kernel<uint16_t, 1>), dim3(blocks), dim3(256), 0, s, a, rows);
+  if (kv_f32) hipLaunchKernelGGL((qknorm_rope_kv_kernel<float>), dim3(blocks), dim3(256), 0, s, a, rows);
+  else hipLaunchKernelGGL((qknorm_rope_kv_kernel<uint16_t>), dim3(blocks), dim3(256), 0, s, a, rows);
   return nullptr;
 }
-const char* launch_rope_compare(const RopeKvArgs& a, const RopeKvArgs& b, int rows, int layer, unsigned* counters, void* log,
-                                int max_log, hipStream_t s) {
-  if (rows <= 0) return nullptr;
-  const long nvec = (long)rows * (a.n_q + 2 * a.n_kv);
-  hipLaunchKernelGGL(rope_compare_kernel, dim3((int)((nvec + 3) / 4)), dim3(256), 0, s, a, b, rows, layer, counters,
-                     (unsigned char*)log, max_log);
-  return nullptr;
-}
-
 const char* launch_argmax_partials(const float* logits, int V, int S, float* pval, int* pidx, int stride, int nblk,
                                    hipStream_t s) {
   if (S <= 0) return nullptr;

@@ -516,287 +516,14 @@ __global__ __launch_bounds__(256, NS == 3 ? 3 : 2) void fattn_dma_kernel(AttnArg
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Round 5: the same kernel software-pipelined by hand (knob Q3A_FATTN_PIPE).  In fattn_dma_kernel a tile is ONE
-// dependent chain per wave -- 8 QK MFMAs into one score accumulator -> max -> exp -> pack -> 8 PV MFMAs -- and with two or three
-// waves per SIMD nothing hides it: the PMC pass shows the matrix pipe 15 % busy and 36 % of the wave cycles waiting on the previous
-// instruction.  Here the wave keeps TWO score register sets: while the eight QK MFMAs of tile t + 1 run into `nxt` (each waits for
-// the one before it: same accumulator), the softmax VALU of tile t on `cur` is issued between them in eight hand-cut pieces
-// (mask + max, reduce + alpha, 4 x four exponentials, sum + pack, pack + first V reads), fenced with sched_barrier so hipcc keeps
-// the order; then the eight PV MFMAs of tile t.  The ring protocol shifts by one tile: iteration t reads K(t + 1) and V(t), so its
-// barrier means "tile t + 1 is whole, everybody is done with tile t - 1", and the ring has NS = 4 stages to keep two tiles in flight
-// (64 KiB at HD = 128; with ~200 registers per lane two workgroups per CU either way).  Same arithmetic as fattn_dma_kernel in the
-// same order per query: bit-identical results (tests: test_mfma_attention_matches_valu_attention, pipe knob on / off).
-template <int HD, int GROUP, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void fattn_pipe_kernel(AttnArgs a) {
-  constexpr int NS = 4;
-  constexpr int KT = 32;
-  constexpr int QTILES = 4 / GROUP, QT = 32 * QTILES;
-  constexpr int KS = HD / 16, DT = HD / 32;
-  constexpr int ROW_B = HD * 2;
-  constexpr int RPP = 1024 / ROW_B;
-  constexpr int CPR = HD / 8;
-  constexpr int PIECES = KT / RPP;
-  constexpr int PPW = PIECES / 4;
-  constexpr int OPB = KT * ROW_B;
-  constexpr int STAGE = 2 * OPB;
-  static_assert(PPW >= 1, "tile too small for four waves");
-  static_assert(KS == 8 || KS == 4, "head dim 128 or 64");
-  __shared__ __attribute__((aligned(1024))) uint8_t ring[NS * STAGE];  // the ONLY LDS object: [stage][K | V][row][HD]
-
-  const AttnSeg seg = a.segs[blockIdx.z];
-  const int kvh = blockIdx.y;
-  const int qb0 = blockIdx.x * QT;
-  if (qb0 >= seg.len) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  const int g = wave % GROUP, qs = wave / GROUP;
-  const int head = kvh * GROUP + g;
-  const int q0 = qb0 + qs * 32, qi = q0 + l31;
-  const bool wave_has_q = q0 < seg.len;
-  const uint16_t* kbase = reinterpret_cast<const uint16_t*>(a.k) + seg.kv_off + (int64_t)kvh * a.kv_hs;
-  const uint16_t* vbase = reinterpret_cast<const uint16_t*>(a.v) + seg.kv_off + (int64_t)kvh * a.kv_hs;
-
-  const int block_qmax = min(qb0 + QT, seg.len) - 1;
-  const int n_keys = CAUSAL ? block_qmax + 1 : seg.len;
-  const int n_tiles = (n_keys + KT - 1) / KT;
-  const int wave_qmax = min(q0 + 32, seg.len) - 1;
-  // tiles this wave consumes: those that hold a key some query of the wave may see (wave-uniform)
-  const int n_w = __builtin_amdgcn_readfirstlane(!wave_has_q ? 0 : (CAUSAL ? min(n_tiles, wave_qmax / KT + 1) : n_tiles));
-
-  const int prow = lane / CPR, pc = lane % CPR;
-  int srcK[PPW], srcV[PPW], rowt[PPW];
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int p = wave * PPW + i, r = p * RPP + prow;
-    rowt[i] = r;
-    srcK[i] = HD == 128 ? (pc ^ (r & 15)) : (pc ^ ((r >> 1) & 7));
-    const int b = pc >> 1, bs = HD == 128 ? (b ^ (2 * (r & 3))) : (b ^ (r & 2));
-    srcV[i] = (bs << 1) | (pc & 1);
-  }
-  const int last_key = seg.len - 1;
-  auto issue = [&](int t) {
-    uint8_t* st = ring + (t % NS) * STAGE;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int key = min(t * KT + rowt[i], last_key);
-      const int p = wave * PPW + i;
-      __builtin_amdgcn_global_load_lds((fa_gptr_t)(kbase + (int64_t)key * a.kv_rs + srcK[i] * 8), (fa_lptr_t)(st + p * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((fa_gptr_t)(vbase + (int64_t)key * a.kv_rs + srcV[i] * 8), (fa_lptr_t)(st + OPB + p * 1024), 16, 0, 0);
-    }
-  };
-  constexpr int PER_TILE = 2 * PPW;
-#pragma unroll
-  for (int t = 0; t < NS; ++t)  // every stage is free at the start: NS tiles requested up front
-    if (t < n_tiles) issue(t);
-
-  bf16x8_t qfrag[KS];
-  {
-    const uint16_t* qrow = a.q16 + (size_t)(seg.q_row0 + (qi < seg.len ? qi : seg.len - 1)) * a.q_rs + head * HD;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qfrag[ks] = *reinterpret_cast<const bf16x8_t*>(qrow + ks * 16 + half * 8);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qfrag[ks]));
-  }
-
-  f32x16_t oacc[DT];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-  float mrun = -INFINITY, lrun = 0.f;
-  const float scale2 = 1.44269504088896340736f / a.scale_div;
-
-  int koff[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int c = ks * 2 + half;
-    koff[ks] = l31 * ROW_B + ((HD == 128 ? (c ^ (l31 & 15)) : (c ^ ((l31 >> 1) & 7))) << 4);
-  }
-  const int vr = (lane & 15) >> 2, vu = lane & 3, db = (lane >> 4) & 1;
-  unsigned voff[DT];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) {
-    const int b = dt * 2 + db, bs = HD == 128 ? (b ^ (2 * vr)) : (b ^ (vr & 2));
-    voff[dt] = (4 * half + vr) * ROW_B + bs * 32 + vu * 8;
-  }
-
-  // my pieces of tile `want` have landed when at most the tiles issued after it are outstanding; `hi` = last tile issued so far
-  auto wait_tile = [&](int want, int hi) {
-    const int later = min(hi, n_tiles - 1) - want;  // wave-uniform, 0 .. NS - 1
-    if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER_TILE) : "memory");
-    else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_TILE) : "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_TILE) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  typedef unsigned fa_u2 __attribute__((ext_vector_type(2)));
-
-  // ---- one pipeline step: [QK of tile t + 1 into nxt] interleaved with [softmax of tile t on cur], then PV of tile t ----
-  // (The QK half always runs: on the wave's last tile it computes scores of a tile the wave will not use -- eight MFMAs per wave and
-  // launch, on rows that are in LDS either way -- which keeps ONE loop body: with a second, QK-less copy of the step, and the two
-  // register sets alternating over an unrolled pair of steps, hipcc's register allocator at ~250 registers started to copy the
-  // output accumulators between consecutive PV MFMAs.)
-  auto step = [&](f32x16_t& cur, f32x16_t& nxt, const int t) {
-    const uint8_t* stK = ring + ((t + 1) % NS) * STAGE;  // K rows of tile t + 1
-    const uint8_t* stV = ring + (t % NS) * STAGE + OPB;  // V rows of tile t
-    const int key0 = t * KT;
-    const bool full = key0 + 31 <= (CAUSAL ? min(q0, seg.len - 1) : seg.len - 1);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) nxt[r] = 0.f;
-    float tmax = -INFINITY, psum = 0.f, alpha = 1.f, m_new, m_use;
-    bool rescale = false;
-    bf16x8_t pfrag[2];
-    fa_u2 vt[DT][4];
-    const unsigned vstage = (unsigned)(size_t)stV;
-    auto tr_reads = [&](int dt) {
-      const unsigned ad = vstage + voff[dt];
-      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[dt][0]) : "v"(ad) : "memory");
-      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[dt][1]) : "v"(ad), "n"(8 * ROW_B) : "memory");
-      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[dt][2]) : "v"(ad), "n"(16 * ROW_B) : "memory");
-      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[dt][3]) : "v"(ad), "n"(24 * ROW_B) : "memory");
-    };
-    // the eight softmax pieces of tile t (HD = 64 has four QK MFMAs: two pieces behind each)
-    auto piece = [&](int i) {
-      if (i == 0) {  // mask (diagonal / last tile only) + maximum of the first eight scores
-        if (!full) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const bool valid = key < seg.len && (!CAUSAL || key <= qi);
-            cur[r] = valid ? cur[r] : -INFINITY;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) tmax = fmaxf(tmax, cur[r]);
-      } else if (i == 1) {  // rest of the maximum, cross-half reduce, new running maximum, rescale factor
-#pragma unroll
-        for (int r = 8; r < 16; ++r) tmax = fmaxf(tmax, cur[r]);
-        tmax *= scale2;
-        tmax = xor32_max(tmax);
-        m_new = fmaxf(mrun, tmax);
-        rescale = __builtin_amdgcn_ballot_w64(m_new > mrun) != 0;
-        m_use = fmaxf(m_new, -1e30f);
-        if (rescale) alpha = __builtin_amdgcn_exp2f(mrun - m_use);
-      } else if (i <= 5) {  // four exponentials per piece
-#pragma unroll
-        for (int r = (i - 2) * 4; r < (i - 1) * 4; ++r) {
-          cur[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[r], scale2, -m_use));
-          psum += cur[r];
-        }
-      } else if (i == 6) {  // row sum, running sum, first half of P^T as bf16
-        psum = xor32_sum(psum);
-        lrun = lrun * alpha + psum;
-        mrun = m_new;
-        uint4 p;
-        p.x = pack_bf16x2(cur[0], cur[1]); p.y = pack_bf16x2(cur[2], cur[3]); p.z = pack_bf16x2(cur[4], cur[5]); p.w = pack_bf16x2(cur[6], cur[7]);
-        pfrag[0] = *reinterpret_cast<const bf16x8_t*>(&p);
-      } else {  // second half of P^T, first V^T reads
-        uint4 p;
-        p.x = pack_bf16x2(cur[8], cur[9]); p.y = pack_bf16x2(cur[10], cur[11]); p.z = pack_bf16x2(cur[12], cur[13]); p.w = pack_bf16x2(cur[14], cur[15]);
-        pfrag[1] = *reinterpret_cast<const bf16x8_t*>(&p);
-        tr_reads(0);
-      }
-    };
-    // (the sum psum accumulates the sixteen probabilities in the order r = 0 .. 15, as fattn_dma_kernel does)
-    {
-      bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(stK + koff[0]);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        bf16x8_t kf_next = kf;
-        if (ks + 1 < KS) kf_next = *reinterpret_cast<const bf16x8_t*>(stK + koff[ks + 1]);
-        nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfrag[ks], nxt, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (KS == 8) piece(ks);
-        else { piece(2 * ks); piece(2 * ks + 1); }
-        __builtin_amdgcn_sched_barrier(0);
-        kf = kf_next;
-      }
-    }
-    // ---- O^T[d][query] = alpha * O^T + sum_key V[key][d] P[key][query] ----
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      if (rescale) {
-        asm volatile("" ::: "memory");  // keeps this a BRANCH (see fattn_dma_kernel)
-        oacc[dt] *= alpha;
-      }
-      if (dt + 1 < DT) {
-        tr_reads(dt + 1);
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vt[dt][0]), "+v"(vt[dt][1]), "+v"(vt[dt][2]), "+v"(vt[dt][3])::"memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[dt][0]), "+v"(vt[dt][1]), "+v"(vt[dt][2]), "+v"(vt[dt][3])::"memory");
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const uint4 v = make_uint4(vt[dt][kk * 2].x, vt[dt][kk * 2].y, vt[dt][kk * 2 + 1].x, vt[dt][kk * 2 + 1].y);
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v), pfrag[kk], oacc[dt], 0, 0, 0);
-      }
-    }
-  };
-
-  // ---- prologue: scores of tile 0 ----
-  f32x16_t sA, sB;
-  wait_tile(0, NS - 1);
-  asm volatile("s_barrier" ::: "memory");  // tile 0 is whole
-  if (n_w > 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sA[r] = 0.f;
-    const uint8_t* st0 = ring;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(st0 + koff[ks]);
-      sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfrag[ks], sA, 0, 0, 0);
-    }
-  }
-  // ---- main loop: iteration t needs tile t + 1 whole (its K) and frees tile t - 1 ----
-  auto sync_for = [&](int t) {  // workgroup-uniform
-    if (t + 1 < n_tiles) {
-      wait_tile(t + 1, t == 0 ? NS - 1 : t - 2 + NS);
-      asm volatile("s_barrier" ::: "memory");  // tile t + 1 is whole; every wave is done with iteration t - 1 (tile t - 1's V, tile t's K)
-      if (t >= 1 && t - 1 + NS < n_tiles) issue(t - 1 + NS);
-    }
-  };
-  // (two steps per trip so that the score sets swap roles by NAME: with `sA = sB` at the end of one step hipcc folded the copy into
-  // the QK chain -- seven MFMAs into sB, a wait for them, eight moves, the eighth MFMA into sA)
-  for (int t = 0; t < n_tiles; t += 2) {
-    sync_for(t);
-    if (t < n_w) step(sA, sB, t);
-    if (t + 1 < n_tiles) {
-      sync_for(t + 1);
-      if (t + 1 < n_w) step(sB, sA, t + 1);
-    }
-  }
-  // ---- write O[query][d] = O^T / l ----
-  if (wave_has_q && qi < seg.len) {
-    const float inv = 1.0f / lrun;
-    float* orow = a.o + (size_t)(seg.q_row0 + qi) * a.o_rs + head * HD;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int d = dt * 32 + 8 * r4 + 4 * half;
-        const float4 v = make_float4(oacc[dt][4 * r4] * inv, oacc[dt][4 * r4 + 1] * inv, oacc[dt][4 * r4 + 2] * inv, oacc[dt][4 * r4 + 3] * inv);
-        if (a.o16) {
-          uint2 pk;
-          pk.x = pack_bf16x2(v.x, v.y);
-          pk.y = pack_bf16x2(v.z, v.w);
-          *reinterpret_cast<uint2*>(a.o16 + (size_t)(seg.q_row0 + qi) * a.o_rs + head * HD + d) = pk;
-        } else {
-          *reinterpret_cast<float4*>(orow + d) = v;
-        }
-      }
-  }
-}
-
 template <int HD, int GROUP, bool CAUSAL>
 void launch_dma(const AttnArgs& a, hipStream_t s) {
   constexpr int QT = 32 * (4 / GROUP);
   dim3 grid((a.max_len + QT - 1) / QT, a.n_kv_heads, a.n_segs);
   // ring depth: 3 stages = 48 KiB at HD = 128, three workgroups per CU (A/B knob Q3A_FATTN_NS=4: 64 KiB, two per CU)
   static const int ns = [] { const char* e = getenv("Q3A_FATTN_NS"); return e ? atoi(e) : 3; }();
-  // A/B knob fattn_pipe (Q3A_FATTN_PIPE / q3a_debug_set): the software-pipelined form (fattn_pipe_kernel)
-  const bool pipe = knobs().fattn_pipe.load(std::memory_order_relaxed) != 0;
-  if (pipe) { hipLaunchKernelGGL((fattn_pipe_kernel<HD, GROUP, CAUSAL>), grid, dim3(256), 0, s, a); return; }
+  // (round 5's hand-pipelined form of this kernel -- second score register set, softmax of tile t between the QK MFMAs of tile t + 1 --
+  // was bit-identical and slower, 64.2 vs 60.5 us per prefill layer; removed in round 6, docs/HISTORY.md, last present at commit caf7a05)
   if (ns == 4) hipLaunchKernelGGL((fattn_dma_kernel<HD, GROUP, CAUSAL, 4>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((fattn_dma_kernel<HD, GROUP, CAUSAL, 3>), grid, dim3(256), 0, s, a);
 }

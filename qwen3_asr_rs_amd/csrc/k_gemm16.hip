@@ -13,7 +13,7 @@
 //     (2 x 2), each wave (BM/32) x (BN/32) fragments of v_mfma_f32_16x16x32_bf16;
 //   * K loop, two LDS buffers: one barrier per K tile (its workgroup release carries the vmcnt(0) that lands the
 //     LDS-DMA issued one iteration earlier), then the next tile's loads are issued and fly under this tile's MFMAs;
-//   * knob "gemm16_ring" (on by default since round 4; 0 = the two-buffer loop above): NS = 3 / 4 (64x64 / 32x64 tiles of dense operands, launches of
+//   * (always since round 6; rounds 3-5 kept the two-buffer loop above selectable by the knob gemm16_ring) NS = 3 / 4 (64x64 / 32x64 tiles of dense operands, launches of
 //     up to 768 / 512 workgroups): a ring of LDS stages with two / three K tiles in flight and a COUNTED vmcnt in front of a raw s_barrier.  With two stages a K step costs
 //     one full L2 round trip for eight MFMAs per wave: on the one-clip shapes (M ~ 400: 300-700 workgroups, 14-16 K steps)
 //     the K loop took 9-10.5 us per workgroup, 4.9-5.9 us through the ring (profiles/r3_phase_probe_one_clip_gemms.txt);
@@ -567,18 +567,17 @@ __global__ __launch_bounds__(256) void gemm16k_kernel(ALoader A, const uint16_t*
 template <int BM, int BN, int BK, bool GLU, class ALoader>
 void launch16(const ALoader& A, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  // Dense operands, BK = 64, tiles up to 64x64, knob "gemm16_ring" (default on; Q3A_GEMM16_RING=0: two stages): a ring of
+  // Dense operands, BK = 64, tiles up to 64x64, (the A/B knob gemm16_ring of rounds 3-5 is gone: the ring won) a ring of
   // LDS stages as deep as still lets every workgroup of the launch be resident at once (64x64: 16 KiB per stage, 160 KiB per
   // CU) -- four stages up to 2 workgroups per CU, three up to 3; beyond that (e.g. the lm_head of a batched decode step,
   // 2374 workgroups) residency is worth more than depth: two.
   constexpr bool ring = std::is_same<ALoader, DenseA16>::value && BK == 64 && BM <= 64 && BN <= 64;
-  const bool two_stage = knobs().gemm16_ring.load() == 0;
   if constexpr (ring) {
-    if (!two_stage && tiles <= 512) {
+    if (tiles <= 512) {
       hipLaunchKernelGGL((gemm16_kernel<BM, BN, BK, GLU, ALoader, 4>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
       return;
     }
-    if (!two_stage && tiles <= 768) {
+    if (tiles <= 768) {
       hipLaunchKernelGGL((gemm16_kernel<BM, BN, BK, GLU, ALoader, 3>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
       return;
     }
@@ -644,14 +643,12 @@ const char* launch_gemm16_small(const uint16_t* X, int lda, const uint16_t* W, i
     const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
     // K steps of 256 in two stages (32 KiB in flight per workgroup); where 256 does not divide K (the encoder's d_model 896)
     // steps of 128 in a ring of four stages (48 KiB in flight) instead of two (16 KiB): 6.5 vs 7.9 us on enc out.  The ring
-    // measured no gain over the 256-steps (profiles/r3_phase_probe_one_clip_gemms.txt).  Knob "gemm16_ring" (default on).
-    const bool two_stage = knobs().gemm16_ring.load() == 0;
+    // measured no gain over the 256-steps (profiles/r3_phase_probe_one_clip_gemms.txt).
     // (Measured and dropped: 32x64 tiles, at most one per CU, ring of four 128-steps -- the launch then moves 96 instead of
     // 2 x 64 operand rows per K step on its busiest CUs, but 48-74 CUs idle: 926 vs 930 us over the 92 launches of a clip.
     // These launches run at ~75 GB/s of LDS-DMA per CU whatever the tile, profiles/r3_phase_probe_one_clip_gemms.txt.)
     if (K % 256 == 0) hipLaunchKernelGGL((gemm16k_kernel<32, 256, DenseA16, 2>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
-    else if (!two_stage) hipLaunchKernelGGL((gemm16k_kernel<32, 128, DenseA16, 4>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
-    else hipLaunchKernelGGL((gemm16k_kernel<32, 128, DenseA16, 2>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
+    else hipLaunchKernelGGL((gemm16k_kernel<32, 128, DenseA16, 4>), dim3(tiles), dim3(256), 0, s, A, W, M, N, K, ep);
     return nullptr;
   }
   static const bool force_bk32 = [] { const char* e = getenv("Q3A_GEMM16_BK32"); return e && atoi(e) != 0; }();  // A/B knob

@@ -123,7 +123,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 template <bool GLU, class ALoader, bool ROPE = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16_t* __restrict__ Wt,
                                                          const uint16_t* __restrict__ zero, int M, int N, int K, GemmEpilogue ep,
-                                                         RopeKvArgs rk, int resid_prefetch) {
+                                                         RopeKvArgs rk) {
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * G_BUF];  // the ONLY LDS object of this kernel
 
   Q3A_STAMP_AT(ep.stamp, blockIdx.x, 0);  // entry
@@ -325,9 +325,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
     // 22 GB/s) next to 16.6 us of K loop at K = 896.  Here the 16 residual rows of a pass are requested back to back: pass 0's as
     // soon as pass 0's accumulators are staged (their registers take the rows), so pass 1 never waits for its rows and pass 0
     // waits for one round trip, row by row (counted vmcnt).  Addresses = wave-uniform row base + ONE per-lane byte offset.  M % 4 == 0: the 4 rows of an
-    // iteration are inside or outside the matrix together.  Same arithmetic ((acc + bias) + residual).  Knob: gemm256_resid_prefetch.
-    if (ep.resid != nullptr && ep.out16 == nullptr && ep.rowmap == nullptr && ep.addend == nullptr && ep.act == 0 && (M & 3) == 0 &&
-        resid_prefetch != 0) {  // kernel-uniform
+    // iteration are inside or outside the matrix together.  Same arithmetic ((acc + bias) + residual): bit-identical to the general loop (round 4 A/B, knob removed in round 6).
+    if (ep.resid != nullptr && ep.out16 == nullptr && ep.rowmap == nullptr && ep.addend == nullptr && ep.act == 0 && (M & 3) == 0) {  // kernel-uniform
       const int n = n0 + wc * 64 + (lane & 15) * 4;
       const unsigned voff = ((unsigned)(lane >> 4) * (unsigned)ep.ldo + (unsigned)(n < N ? n : 0)) * 4u;
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -643,8 +642,7 @@ template <bool GLU, class ALoader, bool ROPE = false>
 void launch256(const ALoader& A, const uint16_t* W, const uint16_t* zero, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s,
                const RopeKvArgs& rk = RopeKvArgs{}) {
   const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-  hipLaunchKernelGGL((gemm256_kernel<GLU, ALoader, ROPE>), dim3(tiles), dim3(512), 0, s, A, W, zero, M, N, K, ep, rk,
-                     knobs().gemm256_resid_prefetch.load(std::memory_order_relaxed));
+  hipLaunchKernelGGL((gemm256_kernel<GLU, ALoader, ROPE>), dim3(tiles), dim3(512), 0, s, A, W, zero, M, N, K, ep, rk);
 }
 
 }  // namespace
@@ -719,7 +717,6 @@ const char* launch_gemm256_qkrope(const uint16_t* X, int lda, const uint16_t* W,
     GemmEpilogue e2;
     e2.out = rk.qkv; e2.ldo = N; e2.bias = bias;  // rk.qkv: fp32 scratch [>= M - M1][N]
     if (const char* err = launch_gemm16_small(X + (size_t)M1 * lda, lda, W, M - M1, N, K, e2, false, s)) return err;
-    if (rk.dbg_scratch_copy) (void)hipMemcpyAsync(rk.dbg_scratch_copy, rk.qkv, (size_t)(M - M1) * N * 4, hipMemcpyDeviceToDevice, s);  // (bisect_layers.py)
     RopeKvArgs r2 = rk;
     r2.row_seq += M1; r2.row_pos += M1; r2.q16 += (size_t)M1 * rk.n_q * 128;
     return launch_qknorm_rope_kv(r2, M - M1, false, s);

@@ -393,7 +393,7 @@ void launch_k(const SkinnyArgs& a, dim3 grid, hipStream_t s) {
     // more pair tiles than CUs and the output columns divide into 3 half pairs per workgroup with at most one workgroup per CU
     // (hidden 2048 / inter 6144: 256 workgroups): balanced half-pair form, the K slice in passes of 4 steps (96 KiB of LDS).
     // glu_hp3: 1 = when it balances (default), 0 = never (A/B), 2 = whenever the shape allows (tests at small shapes)
-    static const int n_cu_hp = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    const int n_cu_hp = a.n_cu > 0 ? a.n_cu : 256;  // the ENGINE's device (a function-local static cached whichever device the first caller had: ADVICE r5)
     const int inter = a.N / 2;
     const bool shape_ok = wlds_on && a.N % 32 == 0 && inter % 24 == 0 && per % 4 == 0 && steps % per == 0 && steps == per * SK_WAVES;
     const bool balances = (int)grid.x > n_cu_hp && inter / 24 <= n_cu_hp;
@@ -405,10 +405,10 @@ void launch_k(const SkinnyArgs& a, dim3 grid, hipStream_t s) {
   }
   if constexpr (TILES == 2 && UNR % 4 == 0 && UNR >= 8 && !SPLIT && XMODE >= 2) {
     // more workgroups than CUs (gate/up at hidden 2048: 384): two passes of UNR / 2 steps with the partial tile aliased into the
-    // weight region -> 64.5 KiB per workgroup, two resident per CU, no half-empty second round (A/B knob skinny_glu_2pass = 0 -> SkinnyArgs::glu_1pass)
-    const bool two_pass = a.glu_1pass == 0;
-    static const int n_cu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
-    if (wlds_on && two_pass && (int)grid.x > n_cu && per == UNR && steps % per == 0) {
+    // weight region -> 64.5 KiB per workgroup, two resident per CU, no half-empty second round (round 5: 1.428 vs 1.469 ms per step at
+    // 1.7B x 16 against the single-pass form, whose knob is gone)
+    const int n_cu = a.n_cu > 0 ? a.n_cu : 256;
+    if (wlds_on && (int)grid.x > n_cu && per == UNR && steps % per == 0) {
       const size_t wb2 = (size_t)SK_WAVES * TILES * (UNR / 4) * 2048;
       hipLaunchKernelGGL((skinny_kernel<SPLIT, TILES, SH, XMODE, UNR / 2, true, false, true>), grid, block, wb2, s, a);
       return;

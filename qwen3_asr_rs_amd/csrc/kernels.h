@@ -62,17 +62,11 @@ struct Knobs {
   std::atomic<int> decode_parallel_groups{1};   // Q3A_DECODE_PARALLEL: groups as parallel stream / graph branches
   std::atomic<int> fuse_qkrope{1};              // Q3A_FUSE_QKROPE: QK-norm + RoPE + cache append as the qkv GEMM's epilogue
   std::atomic<int> skinny_q{1};                 // Q3A_SKINNY_Q: quarter workgroups for the o / down projections
-  std::atomic<int> fuse_qkv_attn{0};            // Q3A_FUSE_QKV_ATTN: one-sequence decode qkv projection + attention in one launch
   std::atomic<int> eos_run_ahead{1};            // Q3A_EOS_RUN_AHEAD: decode steps kept enqueued ahead of the device in natural-EOS mode.  1: exactly the steps needed are executed; paired with a fixed-N run of the same engine (profiles/r5_eos_run_ahead_ab.txt, two processes): 1 costs +0.03 / +1.24 ms per 100 tokens, 2 costs +2.07 / +1.86 ms (one wasted step + the same launch latency), 3 +1.3 / +1.2, 4 +3.3 / +3.1
-  std::atomic<int> gemm16_ring{1};              // Q3A_GEMM16_RING: 3-4-stage LDS rings with counted vmcnt in the small-M GEMMs (0: two stages, one barrier per K tile)
-  std::atomic<int> skinny_glu_2pass{1};         // Q3A_SKINNY_GLU_2PASS: gate/up skinny GEMM with more workgroups than CUs stages its K slice in two passes, partial tile aliased into the weight region: two workgroups per CU (k_skinny.hip PALIAS)
-  std::atomic<int> dattn_pair_split{0};         // Q3A_DATTN_PAIR_SPLIT: batched decode attention as TWO workgroups per (sequence, kv head) when sequences x kv heads fills at most half the CUs (16 sequences), merged inside the XCD by the second to arrive
   std::atomic<int> skinny_glu_hp3{1};           // Q3A_SKINNY_GLU_HP3: gate/up skinny GEMM as 3 half-pair tiles per workgroup when the pair form has more workgroups than CUs (k_skinny.hip HP; 0 = off, 2 = whenever the shape allows)
-  std::atomic<int> fattn_pipe{0};               // Q3A_FATTN_PIPE: software-pipelined flash attention (k_fattn.hip fattn_pipe_kernel) instead of fattn_dma_kernel
-  std::atomic<int> rope_variant{0};             // Q3A_ROPE_VARIANT (experiment): arithmetic form of qknorm_rope_kv_kernel (dev.h head_norm_rope)
-  std::atomic<int> rope_twice{0};               // Q3A_DEBUG_ROPE_TWICE (debug): re-execute the trailing rows' rope kernel into shadow buffers and compare
-  std::atomic<int> gemm256_resid_prefetch{1};   // Q3A_GEMM256_RESID_PREFETCH: fp32-residual epilogue of gemm256 requests a pass's 16 residual rows ahead of staging it (0: four dependent round trips inside the store loop)
-  std::atomic<int> live_key_splits{1};          // Q3A_LIVE_KEY_SPLITS: one-sequence decode attention launches the key splits the caches HOLD keys for (0: as many as they have room for)
+  // Round 6 removed nine knobs together with the code only they selected (docs/HISTORY.md "Pruned in round 6"; last present at commit
+  // caf7a05): fuse_qkv_attn, dattn_pair_split, fattn_pipe, rope_variant, rope_twice (measured alternatives that lost / finished debug
+  // aids), gemm16_ring, gemm256_resid_prefetch, live_key_splits, skinny_glu_2pass (the winning form is now the only form).
 };
 Knobs& knobs();
 const char* launch_gemm256(const uint16_t* X, int lda, const uint16_t* W, int M, int N, int K, const GemmEpilogue& ep,
@@ -153,15 +147,8 @@ struct RopeKvArgs {
   int n_q, n_kv, max_ctx;
   uint16_t* q16;            // non-null (default mode, MFMA attention): q is written HERE as bf16 [rows][n_q*128] -- the value the
                             // attention kernel rounds it to on load anyway -- instead of in place as fp32 (half the bytes twice)
-  float* dbg_f32 = nullptr;          // debug (knob rope_twice): fp32 copy of what this launch produced, [rows][n_q + 2 n_kv][128]
-  void* dbg_scratch_copy = nullptr;  // debug (Q3A_DEBUG_LAYER_TAPS + Q3A_DEBUG_SCRATCH_COPY): launch_gemm256_qkrope copies the trailing rows'
-                                     // fp32 scratch here BETWEEN the small GEMM and the rope kernel
 };
 const char* launch_qknorm_rope_kv(const RopeKvArgs& a, int rows, bool kv_f32, hipStream_t s);
-// (debug) compare the q / K / V rows two executions of the kernel above wrote (b: shadow buffers); counters[1] += mismatching
-// vectors, each of the first max_log of which leaves a 3584-byte record in log (k_decode.hip)
-const char* launch_rope_compare(const RopeKvArgs& a, const RopeKvArgs& b, int rows, int layer, unsigned* counters, void* log,
-                                int max_log, hipStream_t s);
 // rows [0, M1) of an M x N problem that launch_gemm256 / launch_gemm256_qkrope give to the 256 x 256 kernel when they split off
 // the trailing rows (0: no split)
 int gemm256_split_rows(int M, int N);
@@ -223,7 +210,7 @@ struct SkinnyArgs {
   int qsplit;
   int qs_halves;  // (set by the launcher: 16-sequence halves per row tile)
   int glu_hp3;    // gate/up as 256 workgroups x 3 half-pair tiles (k_skinny.hip HP): 1 = when that balances the CUs (set by the engine from knob skinny_glu_hp3), 0 = never, 2 = whenever the shape allows
-  int glu_1pass;  // 1: keep the gate/up projection's single-pass form even when it has more workgroups than CUs (A/B; knob skinny_glu_2pass = 0)
+  int n_cu;       // compute units of the device the launch goes to (0: 256) -- chooses between the gate/up forms; set by the engine
   int fast_math;  // default mode: hardware rsq / exp / rcp in the RMSNorm scale and SiLU of the epilogue (dev.h rstd_of)
   Q3A_STAMP_FIELD
 };
@@ -264,12 +251,6 @@ struct DecodeAttnArgs {
   uint16_t* out16;             // ... or bf16 (default mode), row-major or, with out_frag, in skinny_frag_index order
   int out_frag;
   int trim_prologue;           // batched kernel: 1 = some sequence of the batch is shorter than the two prologue key tiles, trim them to the live rows too
-  // pair split (k_dattn.hip, PAIR = true): two workgroups per (sequence, kv head), even / odd key tiles, merged by the second to
-  // arrive.  pair_cnt: zeroed words, one per (sequence, kv head), returned to zero by every launch; the partials go to pm / pl / po
-  // ([S][n_q][2] / [S][n_q][2][128]: nsplit >= 2); pair_err counts merges whose partner ran on another XCD (result invalid).
-  unsigned* pair_cnt;
-  unsigned* pair_xcc;          // [S][n_kv][2] XCC_ID of the workgroup that wrote each partial
-  unsigned* pair_err;
   Q3A_STAMP_FIELD
 };
 #ifndef Q3A_DATTN_SPLIT_KEYS
@@ -278,16 +259,6 @@ struct DecodeAttnArgs {
 constexpr int DATTN_KEYS_PER_SPLIT_BF16 = Q3A_DATTN_SPLIT_KEYS, DATTN_KEYS_PER_SPLIT_F32 = 128;
 inline int dattn_keys_per_split(bool kv_f32) { return kv_f32 ? DATTN_KEYS_PER_SPLIT_F32 : DATTN_KEYS_PER_SPLIT_BF16; }
 const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
-// ONE sequence, 8 kv heads x 2 query heads: the qkv projection (RMSNorm fused, as the GEMV) and the attention splits in one
-// launch of 256 workgroups, handed over inside each XCD (k_dattn.hip qkv_attn_kernel).  a.qkv == f.qkv_out.
-struct QkvFuseArgs {
-  const float* x; const float* rms_w; float eps;  // hidden row [K], input-norm weight
-  const uint16_t* W; const float* bias; int K;    // [(n_q + 2 n_kv) * 128][K] bf16, bias or null
-  float* qkv_out;
-  unsigned* sync;                                  // >= 8 * 64 zeroed words, private to one stream
-  unsigned* debug;                                 // optional 8 * 64 words of placement / time-out diagnostics (k_dattn.hip QkvFuse)
-};
-const char* launch_qkv_attn(const DecodeAttnArgs& a, const QkvFuseArgs& f, bool kv_f32, hipStream_t s);
 // one workgroup per (sequence, kv head), online softmax over 128-key tiles, final output written directly (a.out / a.out16)
 const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
 // out[S][n_q*128] = merged partials (needed as its own launch only on the GEMM decode path)

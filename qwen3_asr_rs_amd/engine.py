@@ -302,6 +302,17 @@ class HipGroup:
             pass
 
 
+def measure_peaks(device: int = 0, reps: int = 5) -> dict:
+    """q3a_measure_peaks (include/q3asr.h): HBM read / copy / triad GB/s and the 8192^3 bf16 GEMM TFLOP/s measured on this device."""
+    lib = _lib.load()
+    pk = _lib.Peaks()
+    if lib.q3a_measure_peaks(device, reps, C.byref(pk)) != 0:
+        raise RuntimeError("q3a_measure_peaks failed (no HIP device, or less than 2 GiB of free device memory)")
+    return {"hbm_read_GBps": round(pk.hbm_read_gbps, 1), "hbm_copy_GBps": round(pk.hbm_copy_gbps, 1), "hbm_triad_GBps": round(pk.hbm_triad_gbps, 1),
+            "mfma_bf16_TFLOPs": round(pk.mfma_bf16_tflops, 1), "gemm": [pk.gemm_m, pk.gemm_n, pk.gemm_k], "read_sweep_bytes": int(pk.hbm_read_bytes),
+            "n_cu": pk.n_cu, "best_of": pk.reps}
+
+
 def selftest_gemm16(M: int, N: int, K: int, reps: int = 0, device: int = 0) -> dict:
     """bf16-activation GEMM (global_load_lds path) vs the naive device reference; optional timing of both GEMMs."""
     lib = _lib.load()

@@ -5,6 +5,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

@@ -28,9 +28,11 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = 0.06          # default-mode max |logit error| at 0.6B / 1.7B dims with |logit| <= ~6: 1 % of the logit scale (measured over rounds 4-5:
                           # 0.022-0.046, i.e. 0.4-0.8 %; round 4 carried 0.10 = 2x slack, round 3: 0.05 at |logit| <= 3)
 EMBED_TOL = 2e-2          # rel-L2 of the audio embeddings
-MAX_UNDER_MARGIN = 0.10   # at most this fraction of the compared steps may sit inside the rounding noise (round 3: 0.20 with the
-                          # flat logits of embedding scale 0.02, measured 7-14.5 %; expected ~0 with PEAKED_EMBED_SCALE)
-MAX_FLIPS = 0.05          # fraction of steps whose greedy id may differ from the oracle's (each one justified, see margin_report)
+MAX_UNDER_MARGIN = 0.06   # at most this fraction of the compared steps may sit inside the rounding noise (round 3: 0.20 with the
+                          # flat logits of embedding scale 0.02, measured 7-14.5 %; with PEAKED_EMBED_SCALE the worst measured over rounds
+                          # 4-5 is 5.5 %; round 5 carried 0.10)
+MAX_FLIPS = 0.02          # fraction of steps whose greedy id may differ from the oracle's (each one justified, see margin_report; worst
+                          # measured: 1 flip in 100 steps; round 5 carried 0.05)
 
 
 def rel_l2(got, ref):
@@ -195,6 +197,16 @@ def test_config3_1p7b_batch16_30s_default_mode_sharded():
     _batch_config_check("config3 1.7B B=16", d, 16, {15: 110, 0: 110}, steps=110, free_tokens=110)
 
 
+def test_config4_per_gpu_slice_1p7b_batch32():
+    """BASELINE configs[4]'s per-GPU slice (256 clips over 8 GPUs = 32 per GPU): 1.7B dims, sharded
+    safetensors, 32 x 30 s clips on ONE GPU in the default mode -- the shape every rank of the 8-GPU run executes (utterances are
+    independent, src/inference.rs:89, so the per-rank slice IS the multi-GPU data path).  The first and the last utterance of the
+    slice against per-utterance oracle runs over 110 free-running tokens (context 405 -> 515 keys: the batched decode attention at
+    32 sequences x 8 kv heads crosses the 512-key tile boundary; gate / up on the half-pair form at hidden 2048)."""
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b_peaked", "1.7b", seed=0, shards=2, embed_scale=synthetic.PEAKED_EMBED_SCALE)
+    _batch_config_check("config4 per-GPU slice 1.7B B=32", d, 32, {0: 110, 31: 110}, steps=110, free_tokens=110)
+
+
 def test_1p7b_one_clip_default_mode_gemv_path():
     """1.7B dims at batch 1: the GEMV decode path at K = 2048 / 6144 in the default mode (bench.py --preset 1.7b)."""
     d = synthetic.write_checkpoint("/tmp/q3a_ckpt_1p7b_peaked", "1.7b", seed=0, shards=2, embed_scale=synthetic.PEAKED_EMBED_SCALE)
@@ -208,29 +220,3 @@ def test_1p7b_one_clip_default_mode_gemv_path():
     assert [int(t[0]) for t in T] == ids
     margin_report("1.7B B=1", ids, [l[0] for l in L], ref)
     eng.close()
-
-
-def test_one_launch_qkv_projection_and_attention_inside_each_xcd():
-    """One-sequence decode with the qkv projection and the attention key splits as ONE launch (k_dattn.hip qkv_attn_kernel,
-    off by default): the 32 workgroups of a kv head must all run on one XCD, no wait on the in-XCD arrival counter may run
-    out, and the greedy ids must equal the separate launches' (the projection rows are bit-identical)."""
-    from qwen3_asr_rs_amd import _lib
-    lib = _lib.load()
-    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b_peaked", "0.6b", seed=0, embed_scale=synthetic.PEAKED_EMBED_SCALE)
-    clip = synthetic.synthetic_clip(3, 30.0)
-    ids = {}
-    try:
-        for fuse in (1, 0):
-            assert lib.q3a_debug_set(b"fuse_qkv_attn", fuse) == 0
-            eng = HipEngine(d, 0, debug_taps=True, max_new_tokens=40)
-            ids[fuse] = eng.transcribe_batch([clip], None, max_new=40, fixed_new_tokens=40)[0]
-            if fuse:
-                w = np.frombuffer(eng.debug_read("xcd_sync").tobytes(), dtype=np.uint32).reshape(2, 8, 64)
-                for g in range(8):
-                    assert w[1, g, 32] == 0, f"kv head {g}: {w[1, g, 32]} waits ran out (arrivals seen {w[1, g, 33:37].tolist()})"
-                    assert len(set(w[1, g, :32].tolist())) == 1 and w[1, g, 0] > 0, f"kv head {g}: workgroups on XCCs {sorted(set(w[1, g, :32].tolist()))}"
-                    assert w[0, g, 0] == 0 and w[0, g, 32] == 0   # counters re-armed by the last split to leave
-            eng.close()
-        assert ids[1] == ids[0] and len(ids[0]) == 40
-    finally:
-        lib.q3a_debug_set(b"fuse_qkv_attn", 0)

@@ -114,6 +114,27 @@ def test_oracle_matches_independent_hf_transformers_implementation(tiny_oracle, 
             np.testing.assert_allclose(top.values.numpy(), g[f"{name}_top_val"][s], atol=2e-5)
 
 
+def test_oracle_matches_hf_transformers_pin_at_0p6b_dims():
+    """The same pin at the REAL 0.6B dimensions (round 6): 18 encoder layers x 14 heads, 28 decoder layers,
+    GQA 16 / 8, vocabulary 151 936, a 30 s clip = 4 attention windows (104, 104, 104, 78 tokens), P = 405 -- the checkpoint and the
+    clip bench.py and tests/test_gpu_configs.py use.  HuggingFace's independent implementation and the oracle must agree to fp32
+    rounding through 46 layers: audio embeddings, last-row logits of the prefill, top-4 of 5 steps."""
+    g = np.load(os.path.join(GOLDEN, "hf_pin.npz"))
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b_peaked", "0.6b", seed=0, embed_scale=synthetic.PEAKED_EMBED_SCALE)
+    r = O.AsrOracle(d).transcribe_ids(synthetic.synthetic_clip(0, 30.0), fixed_new_tokens=5, want_taps=True)
+    assert (r.num_audio_tokens, r.prompt_len) == (int(g["0p6b_T"]), 405) == (390, 405)
+    ae = r.taps["audio_embeds"].numpy()
+    scale = float(np.abs(g["0p6b_audio_embeds_q"]).max())
+    np.testing.assert_allclose(ae[::7], g["0p6b_audio_embeds_q"], atol=2e-5 * max(scale, 1.0))
+    lscale = float(np.abs(g["0p6b_logits0_q"]).max())
+    np.testing.assert_allclose(r.step_logits[0].numpy()[::97], g["0p6b_logits0_q"], atol=1e-4 * max(lscale, 1.0))
+    assert r.all_step_ids[:5] == g["0p6b_ids"].tolist()[:5]
+    for s in range(5):
+        top = r.step_logits[s].topk(4)
+        assert top.indices.tolist() == g["0p6b_top_idx"][s].tolist(), s
+        np.testing.assert_allclose(top.values.numpy(), g["0p6b_top_val"][s], atol=1e-4 * max(lscale, 1.0))
+
+
 def test_oracle_stage_goldens(tiny_oracle):
     """per-stage goldens (conv stem, window segments of a 10-chunk input, cos/sin tables, encoder
     and decoder taps, 16 greedy ids) -- tests/golden/oracle_stages.npz, which the HIP engine is held to as well."""

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """A/B of runtime knobs (q3a_debug_set) on ONE engine in ONE process, settings interleaved round by round, PCM resident:
 
-    python tools/ab_knobs.py --preset 1.7b --batch 16 --rounds 3 base skinny_glu_2pass=0 dattn_batched_min_wgs=256
-    python tools/ab_knobs.py --preset 0.6b --batch 32 --rounds 3 base fattn_pipe=1
+    python tools/ab_knobs.py --preset 1.7b --batch 16 --rounds 3 base skinny_glu_hp3=0 dattn_batched_min_wgs=256
+    python tools/ab_knobs.py --preset 0.6b --batch 32 --rounds 3 base skinny_q=0
 
 Every setting is a comma-separated list of key=value (or the word `base`); keys not named in a setting keep their defaults.  Per
 setting: median wall ms per batch, stage times of the last run, decode us per step, and whether the generated ids equal the first
@@ -42,7 +42,7 @@ def main():
                 kv[k] = int(v)
         parsed.append((sset, kv))
     # defaults of every key that some setting touches (restored between settings)
-    known = {"skinny_glu_2pass": 1, "skinny_glu_hp3": 1, "dattn_pair_split": 0, "dattn_batched_min_wgs": 128, "fattn_pipe": 0, "skinny_q": 1, "gemm256_resid_prefetch": 1, "gemm16_ring": 1,
+    known = {"skinny_glu_hp3": 1, "dattn_batched_min_wgs": 128, "skinny_q": 1, "eos_run_ahead": 1,
              "decode_group_size": 0, "decode_parallel_groups": 1, "fuse_qkrope": 1, "gemm256_min_tiles": 128}
     for _, kv in parsed:
         for k in kv:

@@ -1,5 +1,5 @@
-"""What a generous max_new_tokens costs (one 30 s clip, 100 tokens generated, 0.6B dims): run on the GPU box, once as is and
-once with Q3A_LIVE_KEY_SPLITS=0."""
+"""What a generous max_new_tokens costs (one 30 s clip, 100 tokens generated, 0.6B dims): run on the GPU box (the one-sequence decode
+attention launches the key splits the caches HOLD keys for; round 5 measured the alternative behind a knob that is gone)."""
 import sys, time, os
 sys.path.insert(0, os.getcwd())
 import torch

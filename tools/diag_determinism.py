@@ -7,8 +7,7 @@ d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
 clip = synthetic.synthetic_clip(0, 30.0)
 N = 100
 lib = _lib.load()
-for ring in (1, 0):
-    lib.q3a_debug_set(b"gemm16_ring", ring)
+for ring in (1,):  # (rounds 3-5 also ran the two-stage staging here: knob gemm16_ring, gone)
     eng = HipEngine(d, 0, max_new_tokens=N, debug_taps=2)
     outs, lasts = [], []
     for r in range(6):

@@ -342,7 +342,6 @@ int main(int argc, char** argv) {
     const int max_tiles = 1024;
     CHK(hipMalloc(&stamps, (size_t)max_tiles * 8 * sizeof(u64)));
     q3a::knobs().gemm256_min_tiles = 0;
-    if (const char* e = getenv("Q3A_GEMM256_RESID_PREFETCH")) q3a::knobs().gemm256_resid_prefetch = atoi(e);  // A/B of the residual epilogue
     setenv("Q3A_GEMM256_SPLIT_REM", "0", 1);  // every tile in ONE gemm256 launch: the phase means are per tile of that launch
     for (const Shape& sh : shapes) {
       const int tiles = ((sh.M + 255) / 256) * ((sh.N + 255) / 256);
@@ -439,7 +438,6 @@ int main(int argc, char** argv) {
   }
   if (do_small) {
     // ---------------- part 4: the one-clip GEMMs (gemm16 / gemm16k: M ~ 400) ----------------
-    // Q3A_GEMM16_RING=1 in the environment selects the 3-4-stage rings (knob gemm16_ring; default: two stages)
     struct Shape { const char* name; int M, N, K; int epi; bool glu; };  // epi as in part 2
     const Shape shapes[] = {{"enc qkv  390 x 2688 x 896  (bf16 out)", 390, 2688, 896, 0, false}, {"enc fc1  390 x 3584 x 896  (bf16 out, GELU)", 390, 3584, 896, 1, false},
                             {"enc out  390 x  896 x 896  (fp32 residual, K split)", 390, 896, 896, 2, false}, {"enc fc2  390 x  896 x 3584 (fp32 residual, K split)", 390, 896, 3584, 2, false},
@@ -455,9 +453,7 @@ int main(int argc, char** argv) {
     const int max_wgs = 2048;
     CHK(hipMalloc(&stamps, (size_t)max_wgs * 8 * sizeof(u64)));
     q3a::knobs().gemm256_min_tiles = 1 << 30;
-    const char* st_env = getenv("Q3A_GEMM16_RING");
-    q3a::knobs().gemm16_ring = st_env ? atoi(st_env) : 0;
-    printf("\none-clip GEMMs, %s\n", q3a::knobs().gemm16_ring.load() ? "rings of 3-4 LDS stages (Q3A_GEMM16_RING=1)" : "two LDS stages (default)");
+    printf("\none-clip GEMMs, %s\n", "rings of 3-4 LDS stages");
     for (const Shape& sh : shapes) {
       q3a::GemmEpilogue ep;
       ep.ldo = sh.glu ? sh.N / 2 : sh.N; ep.bias = sh.epi == 3 ? nullptr : bias;
