@@ -4,7 +4,9 @@
     python tools/ab_knobs.py --preset 1.7b --batch 16 --rounds 3 base skinny_glu_hp3=0 dattn_batched_min_wgs=256
     python tools/ab_knobs.py --preset 0.6b --batch 32 --rounds 3 base skinny_q=0
 
-Every setting is a comma-separated list of key=value (or the word `base`); keys not named in a setting keep their defaults.  Per
+Every setting is a comma-separated list of key=value (or the word `base`); keys not named in a setting keep their defaults.  A key
+in capitals (Q3A_DATTN_WARM=0) is an ENVIRONMENT variable instead of a q3a_debug_set key -- for round-local experiment switches the
+engine reads at every batch set-up; unset when a setting does not name it.  Per
 setting: median wall ms per batch, stage times of the last run, decode us per step, and whether the generated ids equal the first
 setting's (the knobs here choose between kernels with the same arithmetic; a knob that changes a reduction order may legitimately
 move a near-tie)."""
@@ -39,13 +41,16 @@ def main():
         if sset != "base":
             for item in sset.split(","):
                 k, v = item.split("=")
-                kv[k] = int(v)
+                kv[k] = v if k.isupper() else int(v)
         parsed.append((sset, kv))
+    env_keys = sorted({k for _, kv in parsed for k in kv if k.isupper()})
     # defaults of every key that some setting touches (restored between settings)
     known = {"skinny_glu_hp3": 1, "dattn_batched_min_wgs": 128, "skinny_q": 1, "eos_run_ahead": 1,
              "decode_group_size": 0, "decode_parallel_groups": 1, "fuse_qkrope": 1, "gemm256_min_tiles": 128}
     for _, kv in parsed:
         for k in kv:
+            if k.isupper():
+                continue
             if k not in known:
                 raise SystemExit(f"unknown knob {k} (add its default to tools/ab_knobs.py)")
             defaults[k] = known[k]
@@ -58,8 +63,13 @@ def main():
     def apply(kv):
         for k, v in defaults.items():
             assert lib.q3a_debug_set(k.encode(), v) == 0
+        for k in env_keys:
+            os.environ.pop(k, None)
         for k, v in kv.items():
-            assert lib.q3a_debug_set(k.encode(), v) == 0
+            if k.isupper():
+                os.environ[k] = v
+            else:
+                assert lib.q3a_debug_set(k.encode(), v) == 0
 
     for name, kv in parsed:  # warm-up of every setting (graph capture, first-touch)
         apply(kv)
