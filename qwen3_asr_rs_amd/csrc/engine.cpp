@@ -168,8 +168,6 @@ struct q3a_engine {
   // knobs that shape the decode step, latched per batch in setup_prompts: producers outside the captured graph (prefill
   // finalize, set_tokens) and the captured step must agree on them, and the graph signature names them
   int k_parallel_groups = 1, k_skinny_q = 1, k_dattn_batched_min_wgs = 128, k_skinny_glu_hp3 = 1;
-  int k_dattn_warm_sig = 0;
-  int k_dattn_warm = 7;  // (round-6 A/B, environment Q3A_DATTN_WARM, bit mask: 1 o_proj matrix, 2 down matrix, 4 next layer's K / V rows)
   std::vector<hipStream_t> chain_streams;
   std::vector<hipEvent_t> join_ev;
   hipEvent_t fork_ev = nullptr;
@@ -705,12 +703,6 @@ struct q3a_engine {
       k_parallel_groups = kn.decode_parallel_groups.load(); k_skinny_q = kn.skinny_q.load();
       k_dattn_batched_min_wgs = kn.dattn_batched_min_wgs.load();
       k_skinny_glu_hp3 = kn.skinny_glu_hp3.load();
-      if (const char* e = getenv("Q3A_DATTN_WARM")) k_dattn_warm = atoi(e);
-      {  // (experiment switches of the warm-up duty fold into the latched value so that the graph signature tells settings apart)
-        const char* w = getenv("Q3A_DATTN_WARM_WAVES"); const char* dl = getenv("Q3A_DATTN_WARM_DELAY"); const char* du = getenv("Q3A_DATTN_WARM_DUP");
-        const char* wl = getenv("Q3A_DATTN_WARM_LAYERS");
-        k_dattn_warm_sig = (w ? atoi(w) : 0) + 16 * (dl ? atoi(dl) : 0) + 4096 * (du ? atoi(du) : 0) + 8192 * (wl ? atoi(wl) : 0);
-      }
     }
     const size_t ng = (size_t)n_groups(b);  // groups of <= gsize sequences of the batched decode step
     nn_x.ensure(ng * 32 * H * 2); nn_ss.ensure((size_t)ng * (H / 8) * 32 * 4);  // room for the finer (8-column) partial rows whichever shape the knob selects later
@@ -961,6 +953,7 @@ struct q3a_engine {
       g.x = x; g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
       g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = qkv; g.ldo = QKV;
       timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, ks)); });
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
       GemvArgs o{};
       o.fast_math = precise() ? 0 : 1;
       if (std::min(S, 4) * d.n_q * live_nsplit_ <= GEMV_ATTN_MAX_TABLE) {  // merge the key splits inside the o_proj GEMV
@@ -972,48 +965,16 @@ struct q3a_engine {
       }
       o.ldx = QD; o.W = wh(l.o_w); o.N = H; o.K = QD; o.bias = o_bias ? wf(l.o_b) : nullptr;
       o.mode = 1; o.out = x; o.ldo = H; o.resid = x;
-      GemvArgs dn{};
-      dn.fast_math = precise() ? 0 : 1;
-      dn.x = s_act_g(grp); dn.ldx = I; dn.W = wh(l.down_w); dn.N = H; dn.K = I; dn.bias = mlp_bias ? wf(l.down_b) : nullptr;
-      dn.mode = 1; dn.out = x; dn.ldo = H; dn.resid = x;
-      if (k_dattn_warm != 0) {
-        // The attention launch keeps 8 x S x splits of the CUs busy for ~4 us; the others pull what the NEXT launches stream into
-        // the XCD-local L2s (kernels.h WarmTarget): next layer's K / V rows (this very kernel there), the o_proj matrix, the down
-        // matrix -- in that order, up to a byte budget that the idle CUs move inside the attention's own span.  A GEMV workgroup b
-        // (XCD b % 8) reads the 4 x rows-per-wave rows [b * 4 * pr, ...): one chunk.
-        const size_t budget = (size_t)14 << 20;
-        size_t used = 0;
-        int nw = 0;
-        auto add = [&](const void* base, size_t stride, size_t bytes, size_t chunks) {
-          if (nw < DATTN_WARM_MAX && bytes >= 16 && used + bytes * chunks <= budget) {
-            da.warm[nw++] = WarmTarget{base, (unsigned)stride, (unsigned)(bytes & ~(size_t)15), (unsigned)chunks};
-            used += bytes * chunks;
-          }
-        };
-        if ((k_dattn_warm & 4) && li + 1 < d.dec_layers && d.n_kv == 8)  // one kv head per XCD: a head's live rows are one chunk
-          for (int s = 0; s < S; ++s) {
-            const size_t head = (size_t)max_ctx * 128 * kv_elem();
-            const size_t live = std::min((size_t)live_nsplit_ * dattn_keys_per_split(kv_f32()), (size_t)max_ctx) * 128 * kv_elem();
-            add((uint8_t*)kc_layer(li + 1) + (size_t)(s0 + s) * kv_seq, head, live, d.n_kv);
-            add((uint8_t*)vc_layer(li + 1) + (size_t)(s0 + s) * kv_seq, head, live, d.n_kv);
-          }
-        if (k_dattn_warm & 1) { const size_t rows = 4 * (size_t)gemv_rows_per_wave(o); add(o.W, rows * QD * 2, rows * QD * 2, (size_t)H / rows); }
-        if (k_dattn_warm & 2) { const size_t rows = 4 * (size_t)gemv_rows_per_wave(dn); add(dn.W, rows * I * 2, rows * I * 2, (size_t)H / rows); }
-        da.n_warm = nw;
-        { const char* e = getenv("Q3A_DATTN_WARM_WAVES"); da.warm_waves = e ? atoi(e) : 0; }
-        { const char* e = getenv("Q3A_DATTN_WARM_DELAY"); da.warm_delay = e ? atoi(e) : 0; }
-        { const char* e = getenv("Q3A_DATTN_WARM_DUP"); da.warm_dup = e ? atoi(e) : 0; }
-        da.warm_layers = std::max(0, (n_cu - d.n_kv * S * live_nsplit_) / (d.n_kv * S));
-        if (const char* e = getenv("Q3A_DATTN_WARM_LAYERS")) da.warm_layers = std::min(da.warm_layers, std::max(1, atoi(e)));
-        if (da.warm_layers == 0) da.n_warm = 0;
-      }
-      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
       timed(Q3A_KC_GEMV_O, 2.0 * H * QD, [&] { KCHK(launch_gemv(o, S, ks)); });
       GemvArgs u{};
       u.fast_math = precise() ? 0 : 1;
       u.x = x; u.ldx = H; u.rms_w = wf(l.post_ln); u.eps = d.rms_eps; u.W = wh(l.gu_w); u.N = 2 * I; u.K = H;
       u.bias = mlp_bias ? wf(l.gu_b) : nullptr; u.mode = 2; u.out = s_act_g(grp); u.ldo = I;
       timed(Q3A_KC_GEMV, 4.0 * I * H, [&] { KCHK(launch_gemv(u, S, ks)); });
+      GemvArgs dn{};
+      dn.fast_math = precise() ? 0 : 1;
+      dn.x = s_act_g(grp); dn.ldx = I; dn.W = wh(l.down_w); dn.N = H; dn.K = I; dn.bias = mlp_bias ? wf(l.down_b) : nullptr;
+      dn.mode = 1; dn.out = x; dn.ldo = H; dn.resid = x;
       timed(Q3A_KC_GEMV_DOWN, 2.0 * H * I, [&] { KCHK(launch_gemv(dn, S, ks)); });
       return;
     }
@@ -1109,8 +1070,8 @@ struct q3a_engine {
     }
     char buf[256];
     // (one field per latched knob, as latched: packing several into one integer let distinct settings collide -- ADVICE r5)
-    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d.%d.%d/%d/%d/%d/%p/%016llx", B, gsize, k_parallel_groups, k_skinny_q,
-             k_dattn_batched_min_wgs, k_skinny_glu_hp3, k_dattn_warm + 64 * k_dattn_warm_sig, (int)(min_P_ < 256), (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
+    snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d.%d/%d/%d/%d/%p/%016llx", B, gsize, k_parallel_groups, k_skinny_q,
+             k_dattn_batched_min_wgs, k_skinny_glu_hp3, (int)(min_P_ < 256), (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
     return buf;
   }
 

@@ -258,64 +258,8 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
   Q3A_STAMP_AT(a.stamp, stamp_wg, 5);
 }
 
-// ---- L2 warm-up by the workgroups of the extra grid.z layers (kernels.h WarmTarget) -------------------------------------------
-// Warmer `widx` of `nw` on XCD `xcd` (= blockIdx.x: linear block id % 8 with 8 kv heads) walks the 8 KiB units of the chunks
-// c = xcd, xcd + 8, ... of every target, units widx, widx + nw, ...; a lane keeps WARM_NL 16-byte loads in flight, default cache
-// policy (the lines are to STAY in this XCD's L2: the consumers' non-temporal loads then hit there).  The values are folded into
-// a word that is never stored.  Reads only; every address lies inside a target's chunk.
-constexpr int WARM_NL = 8;
-__device__ __forceinline__ void l2_warm(const DecodeAttnArgs& a, const int xcd, const int widx, const int nw) {
-  const int ww = (a.warm_waves >= 1 && a.warm_waves <= DA_WAVES) ? a.warm_waves : DA_WAVES;  // waves of a warmer that load (experiment)
-  if ((int)threadIdx.x >= ww * 64) return;
-  const unsigned UNIT = (unsigned)ww * 64 * 16;  // bytes one workgroup load instruction covers
-  for (int i = 0; i < a.warm_delay; ++i) __builtin_amdgcn_s_sleep(16);  // (experiment) ~0.45 us per step at 2.3 GHz: let the attention's own requests go first
-  unsigned first[DATTN_WARM_MAX + 1], upc[DATTN_WARM_MAX];
-  first[0] = 0;
-#pragma unroll
-  for (int t = 0; t < DATTN_WARM_MAX; ++t) {
-    unsigned units = 0;
-    upc[t] = 1;
-    if (t < a.n_warm && (unsigned)xcd < a.warm[t].n_chunks && a.warm[t].chunk_bytes >= 16) {
-      upc[t] = (a.warm[t].chunk_bytes + UNIT - 1) / UNIT;
-      units = ((a.warm[t].n_chunks - 1 - xcd) / 8 + 1) * upc[t];
-    }
-    first[t + 1] = first[t] + units;
-  }
-  const unsigned total = first[DATTN_WARM_MAX];
-  if (total == 0) return;
-  unsigned acc = 0;
-  for (unsigned u0 = widx; u0 < total; u0 += (unsigned)nw * WARM_NL) {
-    uint4 v[WARM_NL];
-#pragma unroll
-    for (int j = 0; j < WARM_NL; ++j) {
-      unsigned u = u0 + (unsigned)j * nw;
-      if (u >= total) u = (a.warm_dup == 0) ? u0 : (u % total);  // (scalar: the tail of the last round repeats its first unit / somebody else's unit)
-      const char* p = nullptr;  // (u is uniform: the selection below is scalar code; no dynamic index into the kernel arguments)
-      unsigned lim = 16;
-      unsigned off = 0;
-#pragma unroll
-      for (int t = 0; t < DATTN_WARM_MAX; ++t) {
-        if (u >= first[t] && u < first[t + 1]) {
-          const unsigned r = u - first[t], chunk = (unsigned)xcd + 8u * (r / upc[t]);
-          p = reinterpret_cast<const char*>(a.warm[t].base) + (size_t)chunk * a.warm[t].chunk_stride;
-          off = (r % upc[t]) * UNIT;
-          lim = a.warm[t].chunk_bytes;
-        }
-      }
-      v[j] = *reinterpret_cast<const uint4*>(p + min(off + threadIdx.x * 16u, lim - 16u));
-    }
-#pragma unroll
-    for (int j = 0; j < WARM_NL; ++j) acc ^= v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
-  }
-  if (acc == 0x9e3779b9u && a.nsplit < 0) a.pm[0] = 0.f;  // (never true: keeps the loads alive)
-}
-
 template <int GROUP, typename KVT>
 __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnArgs a) {
-  if (blockIdx.z >= (unsigned)a.nsplit) {  // (warm_layers extra layers; uniform per workgroup)
-    l2_warm(a, blockIdx.x, (blockIdx.z - a.nsplit) * gridDim.y + blockIdx.y, (gridDim.z - a.nsplit) * gridDim.y);
-    return;
-  }
   decode_attn_body<GROUP, KVT>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -673,10 +617,10 @@ const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipS
   // have room for: keys beyond the last split are never looked at
   if (a.nsplit <= 0 || (a.nsplit - 1) * dattn_keys_per_split(kv_f32) >= a.max_ctx) return "decode_attn: 1 .. ceil(max_ctx / keys per split) key splits";
   const int group = a.n_q / a.n_kv;
-  if (a.n_warm < 0 || a.n_warm > DATTN_WARM_MAX || a.warm_layers < 0) return "decode_attn: bad warm-up list";
-  for (int t = 0; t < a.n_warm; ++t)
-    if (!a.warm[t].base || a.warm[t].chunk_bytes % 16 != 0 || a.warm[t].chunk_bytes > a.warm[t].chunk_stride) return "decode_attn: warm-up chunks are 16-byte multiples inside their stride";
-  dim3 grid(a.n_kv, S, a.nsplit + (a.n_warm > 0 ? a.warm_layers : 0)), block(DA_WAVES * 64);
+  // (Round 6 measured an L2 warm-up duty here -- the CUs this launch leaves idle pulling the o_proj / down matrices and the next
+  // layer's K / V rows into the XCD-local L2s: -1.4 % per step on one box, +1.2 % on another, every partial form slower; removed,
+  // docs/HISTORY.md 3.2, commit 3ac6499 has the code.)
+  dim3 grid(a.n_kv, S, a.nsplit), block(DA_WAVES * 64);
 #define Q3A_DA(G)                                                                                   \
   do {                                                                                              \
     if (kv_f32) hipLaunchKernelGGL((decode_attn_kernel<G, float>), grid, block, 0, s, a);          \

@@ -251,7 +251,11 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int g, const in
 // load sits under a lane-divergent branch -- out-of-range rows / columns are clamped to valid addresses and voided
 // arithmetically.  (With `row < N ? load : 0` guards hipcc put every weight load into its own exec-masked block with
 // an s_waitcnt vmcnt(0) between them: half of the stream was only requested after the other half had landed.)
-template <int PR, int KI, bool RMS, bool ATTN>
+// MF (ATTN only, at most MF key splits, MF in {4, 8}): the merge's loads -- per-split statistics and partial rows -- are requested
+// IN FRONT of the weight stream.  Loads return in order: behind the weights (MF = 0) the merge starts when the last weight chunk
+// has landed and its exp / scale / LDS round trip / barrier sit exposed between the stream and the FMAs; in front, the partials are
+// back after one L2 round trip and the merged vector is in LDS while the weights are still in flight.
+template <int PR, int KI, bool RMS, bool ATTN, int MF = 0>
 __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   __shared__ float am_v[4][1];
   __shared__ int am_i[4][1];
@@ -296,6 +300,25 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   };
   // Loads return in order.  With a fused norm, x and the norm weight go first: they are back, squared and scaled long
   // before the first weight chunk lands (-0.2 us).  Without one the weights go first (x-first measured +0.2..0.4 us).
+  constexpr int MCH = MF > 0 ? MF : 1;
+  float mg_m[MCH], mg_l[MCH];
+  float4 mg_o0[MCH], mg_o1[MCH];
+  const int mg_k = lane * 8 + wave * 512;            // this wave merges elements mg_k .. mg_k + 7 (it == wave)
+  const bool mg_on = wave < KI && mg_k < K;          // wave-uniform up to the last partial wave of a short K (clamped below)
+  if constexpr (ATTN && MF > 0) {
+    const int kc = mg_k < K ? mg_k : 0;
+    const int h = kc >> 7, d = kc & 127, ns = a.attn_nsplit, base = h * ns;
+#pragma unroll
+    for (int j = 0; j < MCH; ++j) {
+      const int spc = j < ns ? j : ns - 1;  // clamp the address, void the statistics
+      mg_m[j] = a.attn_pm[base + spc];
+      mg_l[j] = a.attn_pl[base + spc];
+      if (j >= ns) mg_m[j] = -INFINITY;
+      mg_o0[j] = *reinterpret_cast<const float4*>(a.attn_po + (size_t)(base + spc) * 128 + d);
+      mg_o1[j] = *reinterpret_cast<const float4*>(a.attn_po + (size_t)(base + spc) * 128 + d + 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the partials' requests stay in front of the weight stream
+  }
   if (RMS) { request_x(); request_w(); } else { request_w(); request_x(); }
   // epilogue operands (bias, residual) ride behind the stream instead of costing an L2 round trip at the very end
   float bv[PR], rv[PR];
@@ -307,7 +330,35 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   }
   __builtin_amdgcn_sched_barrier(0);  // every request is issued before anything is waited for
   Q3A_STAMP_AT(a.stamp, blockIdx.x, 1);  // every load requested
-  if (ATTN) {  // each wave merges a quarter of the vector, once per block
+  if constexpr (ATTN && MF > 0) {  // merge from the registers requested up front (same arithmetic as attn_merge8_ch<FAST, MF>, one chunk)
+    if (mg_on) {
+      const bool fast = a.attn_fast_exp != 0;
+      float Mn = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < MCH; ++j) Mn = fmaxf(Mn, mg_m[j]);
+      float L = 0.f, v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < MCH; ++j) {
+        const float f = fast ? __expf(mg_m[j] - Mn) : expf(mg_m[j] - Mn);  // empty split: exp(-inf) = 0 (split 0 is never empty)
+        L += mg_l[j] * f;
+        v[0] += mg_o0[j].x * f; v[1] += mg_o0[j].y * f; v[2] += mg_o0[j].z * f; v[3] += mg_o0[j].w * f;
+        v[4] += mg_o1[j].x * f; v[5] += mg_o1[j].y * f; v[6] += mg_o1[j].z * f; v[7] += mg_o1[j].w * f;
+      }
+      const float inv = 1.0f / L;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= inv;
+      *reinterpret_cast<float4*>(x_s + mg_k) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(x_s + mg_k + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+      xr[it][0] = *reinterpret_cast<const float4*>(x_s + kk[it]);
+      xr[it][1] = *reinterpret_cast<const float4*>(x_s + kk[it] + 4);
+    }
+  } else if (ATTN) {  // each wave merges a quarter of the vector, once per block
 #pragma unroll
     for (int it = 0; it < KI; ++it) {
       if ((it & 3) == wave && kin[it]) {
@@ -478,7 +529,11 @@ __global__ __launch_bounds__(256) void gemvn_kernel(GemvArgs a) {
 template <int PR, int KI>
 void launch1k(const GemvArgs& a, hipStream_t s) {
   const dim3 grid(gemv_blocks(a)), block(256);
-  if (a.attn_po) hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, true>), grid, block, 0, s, a);
+  // up to 8 key splits (contexts up to 1024 keys): the merge's partials go in FRONT of the weight stream (round 6: -1.2 % per step at
+  // 0.6B x 1 and x 2, neutral at 1.7B; profiles/r6_ab_merge_first.txt); beyond, the chunked merge behind it
+  if (a.attn_po && KI <= 4 && a.attn_nsplit <= 4) hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, true, 4>), grid, block, 0, s, a);
+  else if (a.attn_po && KI <= 4 && a.attn_nsplit <= 8) hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, true, 8>), grid, block, 0, s, a);
+  else if (a.attn_po) hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, true>), grid, block, 0, s, a);
   else if (a.rms_w) hipLaunchKernelGGL((gemv1_kernel<PR, KI, true, false>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, false>), grid, block, 0, s, a);
 }

@@ -234,18 +234,6 @@ __host__ __device__ inline size_t skinny_frag_index(int s, int k) {
   return ((((size_t)(k >> 5) * 2 + (s >> 4)) * 4 + ((k >> 3) & 3)) * 16 + (s & 15)) * 8 + (k & 7);
 }
 
-// L2 warm-up duty of the one-sequence decode attention launch (k_dattn.hip l2_warm): that launch occupies 32-64 of the 256 CUs for
-// ~4 us and moves 2 MB, so the idle CUs pull the operands of the NEXT launches -- the o_proj and down matrices of this layer, the
-// K / V rows of the next layer -- into the L2 of the XCD whose workgroups will read them.  A target is a run of equal chunks;
-// chunk c is read next by a workgroup that the dispatcher places on XCD c % 8 (observed placement, block id % 8: speed only --
-// a wrong guess costs the prefetch, never correctness; nothing is written).
-struct WarmTarget {
-  const void* base;
-  unsigned chunk_stride;   // bytes from one chunk to the next
-  unsigned chunk_bytes;    // live bytes of a chunk (multiple of 16)
-  unsigned n_chunks;
-};
-constexpr int DATTN_WARM_MAX = 6;
 struct DecodeAttnArgs {
   const float* qkv;            // [S][qkv_dim] fp32 (raw projections of the current token)
   const int* pos;              // [S] number of tokens already in the cache = position of the current token
@@ -263,10 +251,6 @@ struct DecodeAttnArgs {
   uint16_t* out16;             // ... or bf16 (default mode), row-major or, with out_frag, in skinny_frag_index order
   int out_frag;
   int trim_prologue;           // batched kernel: 1 = some sequence of the batch is shorter than the two prologue key tiles, trim them to the live rows too
-  // launch_decode_attn only: n_warm targets warmed by warm_layers extra grid.z layers of workgroups (0: none)
-  WarmTarget warm[DATTN_WARM_MAX];
-  int n_warm, warm_layers;
-  int warm_waves, warm_delay, warm_dup;  // (round-6 experiment switches, environment Q3A_DATTN_WARM_{WAVES,DELAY,DUP}; 0 = default)
   Q3A_STAMP_FIELD
 };
 #ifndef Q3A_DATTN_SPLIT_KEYS

@@ -46,7 +46,7 @@ def test_batched_requests_stay_batched_in_the_device_code():
       * gemm256's fp32-residual epilogue requests the 32 residual rows of a tile back to back (before: one `s_waitcnt vmcnt(0)`
         behind each of them -- 16 exposed round trips per 64-row pass);
       * the o_proj GEMV's split merge requests m, l and the partial outputs of a chunk in one batch (hipcc sank l / o below the branch
-        that only needs m);
+        that only needs m); round 6: for up to 8 splits those requests sit IN FRONT of the weight stream, all in one batch with it;
       * the decode qkv / gate-up GEMV requests its whole weight stream before the first wait.
     No GPU: the assembly is what `python -m qwen3_asr_rs_amd.build` keeps."""
     import importlib.util
@@ -65,8 +65,10 @@ def test_batched_requests_stay_batched_in_the_device_code():
         return max([int(n or 1) for n in re.findall(r"\bG(?:x(\d+))?\b", ks[name[0]])] or [0])
 
     assert longest_load_run(r"gemm256_kernelILb0ENS0_9DenseA256ELb0EEE") >= 30      # 32 residual rows (hipcc may move one or two)
-    assert longest_load_run(r"gemv1_kernelILi1ELi4ELb0ELb1EEE") >= 26               # merge: 4 x (m, l, o0, o1) + ... in one batch
-    assert longest_load_run(r"gemv1_kernelILi2ELi2ELb1ELb0EEE") >= 12               # qkv / gate-up: x, norm weight and the weight rows
+    assert longest_load_run(r"gemv1_kernelILi1ELi4ELb0ELb1ELi0EEE") >= 26           # chunked merge (> 8 splits): 4 x (m, l, o0, o1) + ... in one batch
+    assert longest_load_run(r"gemv1_kernelILi1ELi4ELb0ELb1ELi4EEE") >= 20           # <= 4 splits: 16 partial loads, then the 4 weight chunks, no wait between
+    assert longest_load_run(r"gemv1_kernelILi1ELi4ELb0ELb1ELi8EEE") >= 36           # <= 8 splits: 32 + 4
+    assert longest_load_run(r"gemv1_kernelILi2ELi2ELb1ELb0ELi0EEE") >= 12           # qkv / gate-up: x, norm weight and the weight rows
     assert iw.exposed(["G", "W0", "j", "G", "G", "W0", "G", "G", "G", "W0"]) == 2   # the suspects metric itself
 
 
