@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libq3asr_hip.so")
 BIN_DIR = os.path.join(HERE, "bin")
 CLI_PATH = os.path.join(BIN_DIR, "asr")  # the reference's CLI (src/main.rs) on top of the C ABI
 
-SOURCES = ["engine.cpp", "model.cpp", "k_gemm.hip", "k_mel.hip", "k_conv1.hip", "k_norm.hip", "k_attn.hip", "k_decode.hip", "k_gemv.hip", "k_dattn.hip", "k_fattn.hip", "k_skinny.hip", "k_gemm16.hip", "k_gemm256.hip", "k_peaks.hip", "k_fused.hip",
+SOURCES = ["engine.cpp", "model.cpp", "k_gemm.hip", "k_mel.hip", "k_conv1.hip", "k_norm.hip", "k_attn.hip", "k_decode.hip", "k_gemv.hip", "k_dattn.hip", "k_fattn.hip", "k_skinny.hip", "k_gemm16.hip", "k_gemm256.hip", "k_peaks.hip",
            "host_audio.cpp", "host_text.cpp", "host_abi.cpp", "group.cpp", "ops.cpp", "k_ops.hip"]
 HEADERS = ["dev.h", "kernels.h", "model.h", "json.h", "host.h", "ops.h", "unicode_tables.h", os.path.join("..", "..", "include", "q3asr.h"),
            os.path.join("..", "..", "include", "q3asr_ops.h")]

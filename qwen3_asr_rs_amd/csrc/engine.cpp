@@ -156,16 +156,6 @@ struct q3a_engine {
   DevBuf enc_ctx16, dec_ctx16;  // opts.valu_attention in the default mode: bf16 copy of the fp32 attention context
   DevBuf dec_q16;
   int n_cu = 256;
-  // fused qkv + attention launches of the one-sequence decode step (k_dattn.hip qkv_dattn_kernel): [layer][16] arrival counters
-  // (one 64-B line per layer; zeroed at allocation and by every argmax_finalize) + 16 words whose first is the sticky error count
-  DevBuf fuse_sync;
-  static constexpr int kFuseLine = 8 * 16;  // 8 counters, one 64-B line each
-  int k_fuse_qkv_dattn = 0;  // (round-6 A/B: environment Q3A_FUSE_QKV_DATTN: one-sequence form; latched per batch)
-  int k_fuse_batched = 1;    // (round-6 A/B: environment Q3A_FUSE_QKV_DATTN_BATCHED=0 -> the two launches of rounds 1-5; latched per batch)
-  int fuse_groups = 1;
-  size_t fuse_words(size_t ng) const { return ((size_t)d.dec_layers * ng + 1) * kFuseLine; }
-  unsigned* fuse_ready(int li, int grp) const { return fuse_sync.as<unsigned>() + ((size_t)li * fuse_groups + grp) * kFuseLine; }
-  unsigned* fuse_err() const { return fuse_sync.as<unsigned>() + (size_t)d.dec_layers * fuse_groups * kFuseLine; }
   DevBuf n_done;    // device counter of sequences that have produced their EOS (argmax_finalize)
   int* host_prog = nullptr;      // pinned host words written by argmax_finalize (FinalizeArgs::host_progress), polled without a sync
   int* host_prog_dev = nullptr;  // the same words as the device sees them
@@ -713,18 +703,8 @@ struct q3a_engine {
       k_parallel_groups = kn.decode_parallel_groups.load(); k_skinny_q = kn.skinny_q.load();
       k_dattn_batched_min_wgs = kn.dattn_batched_min_wgs.load();
       k_skinny_glu_hp3 = kn.skinny_glu_hp3.load();
-      { const char* e = getenv("Q3A_FUSE_QKV_DATTN"); k_fuse_qkv_dattn = e ? atoi(e) : 0; }
-      { const char* e = getenv("Q3A_FUSE_QKV_DATTN_BATCHED"); k_fuse_batched = e ? atoi(e) : 1; }
     }
     const size_t ng = (size_t)n_groups(b);  // groups of <= gsize sequences of the batched decode step
-    {  // arrival counters of the fused launches: one line set per (layer, group) + the error line (never inside a capture)
-      const size_t bytes = fuse_words(ng) * 4;
-      if (fuse_sync.cap < bytes || !fuse_sync.p) {
-        fuse_sync.ensure(bytes);
-        HIPCHK(hipMemset(fuse_sync.p, 0, fuse_sync.cap));
-      }
-      fuse_groups = (int)ng;
-    }
     nn_x.ensure(ng * 32 * H * 2); nn_ss.ensure((size_t)ng * (H / 8) * 32 * 4);  // room for the finer (8-column) partial rows whichever shape the knob selects later
     x_dec.ensure((size_t)b * H * 4); next_tok.ensure((size_t)b * 4); forced_tok.ensure((size_t)b * 4);
     out_ids.ensure((size_t)b * max_new * 4); step_count.ensure((size_t)b * 4); done.ensure((size_t)b);
@@ -760,7 +740,7 @@ struct q3a_engine {
   // source for DevBuf members and fails when one is missing here.
   std::vector<DevBuf*> step_bufs() {
     return {&kcache, &vcache, &x_dec, &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits,
-            &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po, &nn_x, &nn_ss, &rope_cur, &rope_cos, &rope_sin, &n_done, &forced_tok, &fuse_sync};
+            &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po, &nn_x, &nn_ss, &rope_cur, &rope_cos, &rope_sin, &n_done, &forced_tok};
   }
   std::vector<const DevBuf*> step_bufs() const {
     auto v = const_cast<q3a_engine*>(this)->step_bufs();
@@ -814,7 +794,6 @@ struct q3a_engine {
     f.done = done.as<uint8_t>(); f.n_done = n_done.as<int>(); f.n_seq = S; f.host_progress = host_prog_dev; f.embed = wh(L.embed); f.H = H; f.x_next = x_dec.as<float>(); f.eos0 = kEos0; f.eos1 = kEos1;
     f.cos_t = rope_cos.as<float>(); f.sin_t = rope_sin.as<float>(); f.rope_cur = rope_cur.as<float>();
     f.nn = first_layer_norm_out();
-    if (fuse_sync.p) { f.zero_words = fuse_sync.as<unsigned>(); f.n_zero_words = d.dec_layers * fuse_groups * kFuseLine; }  // (not the error line)
     timed(Q3A_KC_ARGMAX, 0, [&] { KCHK(launch_argmax_finalize(f, S, stream)); });
   }
 
@@ -950,24 +929,6 @@ struct q3a_engine {
     }
   }
 
-  // one sequence, 8 kv heads, hidden 1024 / 2048: qkv projection + attention as one dispatch-ordered launch
-  bool fused_qkv_dattn(int S) const {
-    const int grp = d.n_kv ? d.n_q / d.n_kv : 0;
-    return k_fuse_qkv_dattn != 0 && S == 1 && B == 1 && d.n_kv == 8 && d.n_q == grp * 8 && (grp == 1 || grp == 2 || grp == 4) &&
-           (d.hidden == 1024 || d.hidden == 2048) && d.head_dim == 128 && fuse_sync.p != nullptr;
-  }
-  // a wait of a fused launch that ran out means a projection row was read before it was written: the ids are invalid, so every
-  // way out of the engine fails instead of returning them (never observed; the spin is bounded so that a lost arrival cannot hang)
-  void check_fused_launch() {
-    if (!fuse_sync.p || (!k_fuse_qkv_dattn && !k_fuse_batched)) return;
-    unsigned bad = 0;
-    HIPCHK(hipMemcpy(&bad, fuse_err(), 4, hipMemcpyDeviceToHost));
-    if (bad) {
-      HIPCHK(hipMemset(fuse_sync.p, 0, fuse_sync.cap));
-      fail("fused qkv + attention launch: " + std::to_string(bad) + " wait(s) for projection rows ran out; the generated ids are invalid "
-           "(Q3A_FUSE_QKV_DATTN=0 runs the two launches separately)");
-    }
-  }
   // one decoder layer of the greedy-loop iteration (inference.rs:172-197) for sequences [s0, s0 + S) -- the whole batch on
   // the GEMV path, one group of <= 32 on the skinny MFMA path
   void decode_layer(int li, int grp, int s0, int S, hipStream_t ks) {
@@ -991,18 +952,8 @@ struct q3a_engine {
       g.fast_math = precise() ? 0 : 1;
       g.x = x; g.ldx = H; g.rms_w = wf(l.in_ln); g.eps = d.rms_eps; g.W = wh(l.qkv_w); g.N = QKV; g.K = H;
       g.bias = qkv_bias ? wf(l.qkv_b) : nullptr; g.mode = 0; g.out = qkv; g.ldo = QKV;
-      if (fused_qkv_dattn(S)) {
-        // one launch, ordered by dispatch: projection workgroups first, the attention's key splits behind them (k_dattn.hip)
-        QkvFuseArgs fa{};
-        fa.x = x; fa.rms_w = wf(l.in_ln); fa.eps = d.rms_eps; fa.W = wh(l.qkv_w); fa.bias = g.bias; fa.K = H; fa.qkv_out = qkv;
-        fa.fast_math = g.fast_math;
-        fa.xcd_local = (k_fuse_qkv_dattn & 2) != 0; fa.cnt_stride = (k_fuse_qkv_dattn & 4) ? 16 : 1; fa.dbg_nowait = (k_fuse_qkv_dattn & 8) != 0;
-        fa.ready = fuse_ready(li, grp); fa.err = fuse_err();
-        timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_qkv_dattn(da, fa, kv_f32(), ks)); });
-      } else {
-        timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, ks)); });
-        timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
-      }
+      timed(Q3A_KC_GEMV, 2.0 * QKV * H, [&] { KCHK(launch_gemv(g, S, ks)); });
+      timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
       GemvArgs o{};
       o.fast_math = precise() ? 0 : 1;
       if (std::min(S, 4) * d.n_q * live_nsplit_ <= GEMV_ATTN_MAX_TABLE) {  // merge the key splits inside the o_proj GEMV
@@ -1036,27 +987,15 @@ struct q3a_engine {
     if (pre) { q.xw16f = nn_x_g(grp); q.ss_parts = nn_ss_g(grp); q.ss_nparts = nn_parts(); }
     else q.rms_w = wf(l.in_ln);
     q.bias = qkv_bias ? wf(l.qkv_b) : nullptr; q.mode = 0; q.out = qkv; q.ldo = QKV;
-    const int hgrp = d.n_kv ? d.n_q / d.n_kv : 0;
-    const bool fuse_b = k_fuse_batched != 0 && k_fuse_batched != 3 && b16 && pre && S * d.n_kv >= k_dattn_batched_min_wgs && d.n_kv == 8 && d.n_q == hgrp * 8 &&
-                        (hgrp == 1 || hgrp == 2 || hgrp == 4) && H % 1024 == 0 && d.head_dim == 128 && fuse_sync.p != nullptr;
-    if (fuse_b) {
-      // ONE launch, ordered by dispatch: projection tiles first, the (kv head, sequence) attention workgroups behind them, their
-      // cache-row stream running under the projection (k_fused.hip)
-      da.out16 = reinterpret_cast<uint16_t*>(s_ctx_g(grp)); da.out_frag = 1;
-      da.trim_prologue = min_P_ < 2 * 64;  // (key tiles of 64 there)
-      timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { KCHK(launch_qkv_dattn_batched(q, da, S, fuse_ready(li, grp), k_fuse_batched == 2 ? 1024 + 16 : 16, fuse_err(), ks)); });
-    } else {
     timed(Q3A_KC_GEMM, 2.0 * QKV * H, [&] { KCHK(launch_skinny(q, precise(), ks)); });
     if (S * d.n_kv >= k_dattn_batched_min_wgs) {
       // the group alone fills the chip: one workgroup per (sequence, kv head) walks all keys and writes the context itself
       if (b16) { da.out16 = reinterpret_cast<uint16_t*>(s_ctx_g(grp)); da.out_frag = 1; } else da.out = s_ctx_g(grp);
       da.trim_prologue = min_P_ < 2 * 128;  // some sequence is shorter than the kernel's two prologue key tiles
-      if (k_fuse_batched == 3) da.nsplit = -64;  // (timing experiment: the plain launch with the fused form's 64-key tiles)
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn_batched(da, S, kv_f32(), ks)); });
     } else {
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_decode_attn(da, S, kv_f32(), ks)); });
       timed(Q3A_KC_DECODE_ATTN, 0, [&] { KCHK(launch_attn_combine(da.pm, da.pl, da.po, live_nsplit_, S, d.n_q, s_ctx_g(grp), ks, b16 ? reinterpret_cast<uint16_t*>(s_ctx_g(grp)) : nullptr, b16)); });
-    }
     }
     SkinnyArgs o{};
     o.fast_math = precise() ? 0 : 1;
@@ -1132,7 +1071,7 @@ struct q3a_engine {
     char buf[256];
     // (one field per latched knob, as latched: packing several into one integer let distinct settings collide -- ADVICE r5)
     snprintf(buf, sizeof(buf), "%d.%d.%d.%d.%d.%d.%d.%d/%d/%d/%d/%p/%016llx", B, gsize, k_parallel_groups, k_skinny_q,
-             k_dattn_batched_min_wgs, k_skinny_glu_hp3 + 8 * k_fuse_qkv_dattn + 128 * k_fuse_batched, (int)(min_P_ < 256), (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
+             k_dattn_batched_min_wgs, k_skinny_glu_hp3, (int)(min_P_ < 256), (int)head_logits_, live_nsplit_, max_ctx, max_new, (const void*)arena, (unsigned long long)h);
     return buf;
   }
 
@@ -1286,7 +1225,6 @@ struct q3a_engine {
 
   void fetch_ids(int32_t* out, int stride, int32_t* out_lens) {
     if (!have_prefill) fail("q3a_fetch_ids: nothing generated");
-    check_fused_launch();
     std::vector<int> all((size_t)B * max_new), sc(B);
     HIPCHK(hipMemcpy(all.data(), out_ids.p, all.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(sc.data(), step_count.p, (size_t)B * 4, hipMemcpyDeviceToHost));
@@ -1313,7 +1251,7 @@ struct q3a_engine {
                       &enc_x, &enc_ln, &enc_qkv, &enc_ctx, &enc_ffn, &enc_segs, &audio_embeds, &ids, &audio_rowmap, &row_seq,
                       &row_pos, &dec_segs, &last_rows, &dec_x, &dec_ln, &dec_qkv, &dec_ctx, &dec_act, &kcache, &vcache, &x_dec,
                       &d_pos, &next_tok, &out_ids, &step_count, &done, &s_ln, &s_qkv, &s_ctx, &s_act, &logits, &forced_tok, &part_val, &part_idx, &attn_pm, &attn_pl, &attn_po,
-                      &enc_ctx16, &dec_ctx16, &dec_q16, &zero_page, &rope_cur, &nn_x, &nn_ss, &n_done, &fuse_sync};
+                      &enc_ctx16, &dec_ctx16, &dec_q16, &zero_page, &rope_cur, &nn_x, &nn_ss, &n_done};
     for (auto* b : bufs) b->release();
     for (auto& kv : taps) kv.second.release();
     if (own_arena && arena) (void)hipFree(arena);
@@ -1539,7 +1477,6 @@ int32_t q3a_decode_step(q3a_engine* e, int32_t* next_ids, uint8_t* done, float* 
   e->decode_steps(1);
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipGetLastError());
-  e->check_fused_launch();
   if (next_ids) HIPCHK(hipMemcpy(next_ids, e->next_tok.p, (size_t)e->B * 4, hipMemcpyDeviceToHost));
   if (done) HIPCHK(hipMemcpy(done, e->done.p, (size_t)e->B, hipMemcpyDeviceToHost));
   if (logits_out) HIPCHK(hipMemcpy(logits_out, e->logits.p, (size_t)e->B * e->d.vocab * 4, hipMemcpyDeviceToHost));

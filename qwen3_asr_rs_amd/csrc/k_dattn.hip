@@ -55,18 +55,8 @@ constexpr int DA_WAVES = Q3A_DA_WAVES;  // waves per workgroup; a split is alway
 // (Round 2 built a fused qkv-projection + attention launch on top of this body -- qkv_attn_kernel, handed over inside each XCD --
 // and round 5 a pair-split form of the batched kernel below; both were correct and slower, and were removed in round 6:
 // docs/HISTORY.md, last present at commit caf7a05.)
-// FUSED (qkv_dattn_kernel below): the new token's q / k / v rows are written by OTHER workgroups of the same launch.  The cache rows
-// are requested first; then one lane polls the arrival counter of this kv head's projection rows (relaxed agent-scope loads, bounded),
-// and the rows are read with agent-scope (sc1) loads, which are served past this CU's L1 -- the buffer is reused by every layer, so
-// the L1 may still hold the previous layer's values (cdna_hip_programming.md Guideline 16: sc1 stores + drained flag on the producer,
-// sc1 loads on the consumer).
-struct FuseWait {
-  const unsigned* ready;  // arrival counter of this kv head's producers
-  unsigned need;          // arrivals to wait for
-  unsigned* err;          // += 1 when the wait ran out (the host fails the call: never a silent wrong token, never a hang)
-};
-template <int GROUP, typename KVT, bool FUSED = false>
-__device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const int kvh, const int s, const int sp, const FuseWait fw = FuseWait{}) {
+template <int GROUP, typename KVT>
+__device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const int kvh, const int s, const int sp) {
   constexpr int DPL = Frag16<KVT>::DPL;   // head dims per lane: 8 (bf16) / 4 (f32)
   constexpr int LPK = 128 / DPL;          // lanes per key: 16 / 32
   constexpr int KPI = 64 / LPK;           // keys per load instruction: 4 / 2
@@ -105,13 +95,8 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
   auto load_rows = [&]() {
     if (wave < GROUP + 2) {  // waves 0..GROUP-1: the q heads, GROUP: k, GROUP+1: v
       const int r = wave < GROUP ? kvh * GROUP + wave : (wave == GROUP ? a.n_q + kvh : a.n_q + a.n_kv + kvh);
-      if constexpr (FUSED) {
-        x1 = __hip_atomic_load(row + r * 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        x2 = __hip_atomic_load(row + r * 128 + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        x1 = row[r * 128 + lane];
-        x2 = row[r * 128 + lane + 64];
-      }
+      x1 = row[r * 128 + lane];
+      x2 = row[r * 128 + lane + 64];
     }
   };
   if (wave <= GROUP) {
@@ -121,7 +106,7 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     c = a.rope_cur[(size_t)s * 128 + lane];
     sn = a.rope_cur[(size_t)s * 128 + 64 + lane];
   }
-  if constexpr (!FUSED) load_rows();
+  load_rows();
   // 2. the cache rows, unconditionally (rows at or beyond pos hold stale data and are masked below; the index is
   //    clamped to the allocation)
   const int key_base = key_lo + wave * KEYS_PER_WAVE + kq;
@@ -143,16 +128,6 @@ __device__ __forceinline__ void decode_attn_body(const DecodeAttnArgs& a, const 
     if (tid < GROUP) { a.pm[pbase + (size_t)tid * a.nsplit] = -INFINITY; a.pl[pbase + (size_t)tid * a.nsplit] = 0.f; }
     if (tid < GROUP * 128) a.po[(pbase + (size_t)(tid >> 7) * a.nsplit) * 128 + (tid & 127)] = 0.f;
     return;
-  }
-  if constexpr (FUSED) {
-    if (tid == 0) {
-      unsigned seen = 0;
-      int spins = 0;
-      while ((seen = __hip_atomic_load(fw.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < fw.need && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(2);
-      if (seen < fw.need) atomicAdd(fw.err, 1u);
-    }
-    __syncthreads();
-    load_rows();
   }
   const bool owner = (pos - key_lo) < KEYS_PER_SPLIT;  // the new token lands in this split
 
@@ -289,106 +264,6 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_kernel(DecodeAttnAr
 }
 
 
-// ---- one sequence: qkv projection + attention as ONE launch, ordered by dispatch (round 6) -------------------------------------
-// Workgroups [0, NQ) compute 16 rows each of the qkv projection (8 waves x 2 rows: the arithmetic of gemv1_kernel<2, KI, true,
-// false>, bit-identical rows), workgroups NQ .. NQ + 8 * nsplit are the attention's key splits.  Nothing waits for a workgroup with
-// a HIGHER index: the projection never waits, and an attention workgroup waits only for projection workgroups, which the
-// dispatcher has started before it (workgroups of a grid are dispatched in index order; both sets of a kv head also share
-// blockIdx % 8 = the XCD, so the order argument holds per XCD dispatcher).  What it buys: the kernel boundary between the two
-// launches (1.3 us) and the attention's cache-row round trip (its loads are in flight while the projection runs).  The hand-off is
-// placement-independent: rows are stored with agent-scope (write-through) stores, every storing wave drains them, ONE lane bumps
-// the kv head's counter with an agent-scope RMW; the consumer side is FuseWait above.  Counters are zeroed by argmax_finalize at the
-// end of every step (and by the engine when it allocates them), one counter line per layer.
-struct QkvProj {
-  const float* x; const float* rms_w; float eps;   // hidden row [K] of the token, input-norm weight
-  const uint16_t* W; const float* bias; int K;     // [(n_q + 2 n_kv) * 128][K] bf16, bias or null
-  float* out;                                       // = DecodeAttnArgs::qkv
-  int fast_math;
-  unsigned* ready;                                  // [8] arrival counters of this launch, one per kv head
-  unsigned* err;
-  int xcd_local;                                    // (experiment) hand-off through the XCD's L2: correct only when producers and consumers of a kv head share an XCD
-  int cnt_stride, dbg_nowait;                       // (experiment) words between the kv heads' counters; consumers do not wait (timing only: wrong results)
-};
-__device__ __forceinline__ float qp_dot8(const uint4& w, const float (&x)[8], float s) {  // (k_gemv.hip dot8)
-  f32x2_t a = f32x2_t{bf16lo(w.x), bf16hi(w.x)} * f32x2_t{x[0], x[1]};
-  a += f32x2_t{bf16lo(w.y), bf16hi(w.y)} * f32x2_t{x[2], x[3]};
-  a += f32x2_t{bf16lo(w.z), bf16hi(w.z)} * f32x2_t{x[4], x[5]};
-  a += f32x2_t{bf16lo(w.w), bf16hi(w.w)} * f32x2_t{x[6], x[7]};
-  return s + (a.x + a.y);
-}
-template <int KI>
-__device__ __forceinline__ void qkv_proj_rows(const QkvProj& f, const int row0, unsigned* cnt) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int K = f.K;  // == KI * 512 (launcher)
-  int prow[2];
-  prow[0] = row0 + wave * 2;
-  prow[1] = prow[0] + 1;
-  float4 xr[KI][2], nr[KI][2];
-  uint4 wq[KI][2];
-#pragma unroll
-  for (int it = 0; it < KI; ++it) {  // x and the norm weight first: back, squared and scaled before the first weight chunk lands
-    const int k = lane * 8 + it * 512;
-    xr[it][0] = *reinterpret_cast<const float4*>(f.x + k);
-    xr[it][1] = *reinterpret_cast<const float4*>(f.x + k + 4);
-    nr[it][0] = *reinterpret_cast<const float4*>(f.rms_w + k);
-    nr[it][1] = *reinterpret_cast<const float4*>(f.rms_w + k + 4);
-  }
-#pragma unroll
-  for (int it = 0; it < KI; ++it)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) wq[it][i] = ld_stream16(f.W + (size_t)prow[i] * K + lane * 8 + it * 512);
-  float bv[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) bv[i] = f.bias ? f.bias[prow[i]] : 0.f;
-  __builtin_amdgcn_sched_barrier(0);
-  float x[KI][8];
-  float ss = 0.f;
-#pragma unroll
-  for (int it = 0; it < KI; ++it) {
-    const float4 v0 = xr[it][0], v1 = xr[it][1], w0 = nr[it][0], w1 = nr[it][1];
-    const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { x[it][e] = xv[e]; ss += x[it][e] * x[it][e]; x[it][e] *= wv[e]; }
-  }
-  float acc[2] = {0.f, 0.f};
-#pragma unroll
-  for (int it = 0; it < KI; ++it)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) acc[i] = qp_dot8(wq[it][i], x[it], acc[i]);
-  const float rstd = rstd_of(wave_sum_fast(ss) / (float)K + f.eps, f.fast_math != 0);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float y = wave_sum_fast(acc[i]) * rstd + bv[i];
-    if (lane == 0) {
-      if (f.xcd_local) f.out[prow[i]] = y;  // (experiment) plain store: write-through to THIS XCD's L2
-      else __hip_atomic_store(f.out + prow[i], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through to memory (sc1)
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores ...
-  __syncthreads();
-  if (threadIdx.x == 0) {  // ... then ONE lane counts the workgroup in
-    if (f.xcd_local) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (experiment) RMW resolved in the L2
-    else __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-template <int GROUP, typename KVT, int KI>
-__global__ __launch_bounds__(DA_WAVES * 64) void qkv_dattn_kernel(DecodeAttnArgs a, QkvProj f) {
-  static_assert(DA_WAVES == 8, "16 projection rows per workgroup = 8 waves x 2");
-  constexpr int TQ = GROUP * 8;            // 16-row tiles of a kv head's q rows; + 8 of k + 8 of v
-  const int NQ = 8 * (TQ + 16);            // projection workgroups (8 kv heads)
-  const int b = blockIdx.x;
-  if (b < NQ) {
-    const int h = b & 7, j = b >> 3;       // kv head (= XCD under the observed placement), tile of its TQ + 16
-    const int tile = j < TQ ? TQ * h + j : (j < TQ + 8 ? a.n_q * 8 + 8 * h + (j - TQ) : (a.n_q + a.n_kv) * 8 + 8 * h + (j - TQ - 8));
-    qkv_proj_rows<KI>(f, tile * 16, f.ready + h * f.cnt_stride);
-    return;
-  }
-  const int c = b - NQ;
-  decode_attn_body<GROUP, KVT, true>(a, c & 7, 0, c >> 3, FuseWait{f.ready + (c & 7) * f.cnt_stride, f.dbg_nowait ? 0u : (unsigned)(TQ + 16), f.err});
-}
-
 // ---- batched form: the batch alone fills the chip (S * n_kv >= ~CUs), so one workgroup walks ALL keys of its
 // (sequence, kv head) in 128-key tiles with an online softmax and writes the normalised context itself.  No partials
 // in HBM, no merge launch (at 32 sequences: 15.4 us attention + 4.8 us merge per layer before).  The tile body is the one
@@ -403,9 +278,8 @@ template <bool B> struct BoolC { static constexpr bool value = B; };  // compile
 #ifndef Q3A_DATTN_RING
 #define Q3A_DATTN_RING 2  // tiles in flight per wave (A/B: 2 = one tile ahead 15.3 us per layer at 32 x 500 keys, 3 = 16.6 us)
 #endif
-// FUSED: see FuseWait above (qkv_dattn_batched_kernel, k_fused.hip): the new token's rows come from other workgroups of the launch.
-template <int GROUP, typename KVT, int TILE, int RING_T, bool FUSED>
-__device__ __forceinline__ void decode_attn_batched_body(const DecodeAttnArgs& a, const int kvh, const int s, const FuseWait fw) {
+template <int GROUP, typename KVT, int TILE = 128, int RING_T = Q3A_DATTN_RING>
+__global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(DecodeAttnArgs a) {
   constexpr int DPL = Frag16<KVT>::DPL;
   constexpr int LPK = 128 / DPL;
   constexpr int KPI = 64 / LPK;
@@ -417,13 +291,14 @@ __device__ __forceinline__ void decode_attn_batched_body(const DecodeAttnArgs& a
   __shared__ __attribute__((aligned(16))) KVT v_s[128];
   __shared__ float cm[DA_WAVES][GROUP], cl[DA_WAVES][GROUP];
   __shared__ float co[DA_WAVES][GROUP][128];
-  const int pos = a.pos[s];  // (a scalar load as long as it sits in front of the Q3A_ARG block: see decode_attn_body)
+  const int pos = a.pos[blockIdx.y];  // (a scalar load as long as it sits in front of the Q3A_ARG block: see decode_attn_body)
   // every argument in one scalar-load clause (dev.h Q3A_ARG): the prologue had three scalar round trips in series in front
   // of the first cache-row request
   Q3A_ARG(a.qkv); Q3A_ARG(a.pos); Q3A_ARG(a.q_norm); Q3A_ARG(a.k_norm); Q3A_ARG(a.eps); Q3A_ARG(a.rope_cur); Q3A_ARG(a.kcache); Q3A_ARG(a.vcache);
   Q3A_ARG(a.n_q); Q3A_ARG(a.n_kv); Q3A_ARG(a.max_ctx); Q3A_ARG(a.scale_div); Q3A_ARG(a.out); Q3A_ARG(a.out16); Q3A_ARG(a.out_frag); Q3A_ARG(a.trim_prologue);
+  const int kvh = blockIdx.x, s = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int stamp_wg = s * a.n_kv + kvh;
+  const int stamp_wg = blockIdx.y * gridDim.x + blockIdx.x;
   Q3A_STAMP_AT(a.stamp, stamp_wg, 0);  // entry
   const int sub = lane % LPK, kq = lane / LPK;
   const int qkv_dim = (a.n_q + 2 * a.n_kv) * 128;
@@ -482,12 +357,10 @@ __device__ __forceinline__ void decode_attn_batched_body(const DecodeAttnArgs& a
   // order, so they are back right behind tile 0 -- when they are first needed -- and tile 0 is consumed (and the ring
   // refilled) while tile 1 is still in flight
   float x1 = 0.f, x2 = 0.f, nw1 = 0.f, nw2 = 0.f, c = 0.f, sn = 0.f;
-  const int xrow = wave < GROUP ? kvh * GROUP + wave : (wave == GROUP ? a.n_q + kvh : a.n_q + a.n_kv + kvh);
   if (wave < GROUP + 2) {  // waves 0..GROUP-1: the q heads, GROUP: k, GROUP+1: v
-    if constexpr (!FUSED) {
-      x1 = row[xrow * 128 + lane];
-      x2 = row[xrow * 128 + lane + 64];
-    }
+    const int r = wave < GROUP ? kvh * GROUP + wave : (wave == GROUP ? a.n_q + kvh : a.n_q + a.n_kv + kvh);
+    x1 = row[r * 128 + lane];
+    x2 = row[r * 128 + lane + 64];
     if (wave <= GROUP) {
       const float* nw = wave < GROUP ? a.q_norm : a.k_norm;
       nw1 = nw[lane];
@@ -501,19 +374,6 @@ __device__ __forceinline__ void decode_attn_batched_body(const DecodeAttnArgs& a
   if constexpr (RING > 2) load_tile(2, kr2, vr2, TRIM_PRO, pos);
   if constexpr (RING > 3) load_tile(3, kr3, vr3, TRIM_PRO, pos);
   __builtin_amdgcn_sched_barrier(0);
-  if constexpr (FUSED) {  // the ring is in flight; now wait for this kv head's projection rows and read them past the L1
-    if (tid == 0) {
-      unsigned seen = 0;
-      int spins = 0;
-      while ((seen = __hip_atomic_load(fw.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < fw.need && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(2);
-      if (seen < fw.need) atomicAdd(fw.err, 1u);
-    }
-    __syncthreads();
-    if (wave < GROUP + 2) {
-      x1 = __hip_atomic_load(row + xrow * 128 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      x2 = __hip_atomic_load(row + xrow * 128 + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
   Q3A_STAMP_AT(a.stamp, stamp_wg, 1);  // q/k/v row + first tiles requested
   const int n_tiles = pos / TILE + 1;  // tiles that hold at least one key <= pos
 
@@ -725,11 +585,6 @@ __device__ __forceinline__ void decode_attn_batched_body(const DecodeAttnArgs& a
   Q3A_STAMP_AT(a.stamp, stamp_wg, 5);
 }
 
-template <int GROUP, typename KVT, int TILE = 128, int RING_T = Q3A_DATTN_RING>
-__global__ __launch_bounds__(DA_WAVES * 64) void decode_attn_batched_kernel(DecodeAttnArgs a) {
-  decode_attn_batched_body<GROUP, KVT, TILE, RING_T, false>(a, blockIdx.x, blockIdx.y, FuseWait{});
-}
-
 // merge of the split partials into [S][n_q*128] (only the GEMM decode path needs it as a separate launch)
 __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ pm, const float* __restrict__ pl,
                                                            const float* __restrict__ po, int nsplit, float* __restrict__ out,
@@ -756,7 +611,6 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restri
 
 }  // namespace
 
-#ifndef Q3A_BODY_ONLY  // (k_fused.hip includes this file for the device code above only)
 const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s) {
   if (S <= 0) return nullptr;
   // the caller launches as many splits as the caches HOLD keys for (every pos < nsplit * keys per split), not as many as they
@@ -780,31 +634,6 @@ const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipS
   return nullptr;
 }
 
-const char* launch_qkv_dattn(const DecodeAttnArgs& a, const QkvFuseArgs& fa, bool kv_f32, hipStream_t s) {
-  const int group = a.n_q / a.n_kv;
-  if (a.n_kv != 8 || (group != 1 && group != 2 && group != 4) || a.n_q != group * 8) return "qkv_dattn: 8 kv heads with 1, 2 or 4 query heads each";
-  if (fa.K != 1024 && fa.K != 2048) return "qkv_dattn: hidden size 1024 or 2048";
-  if (a.nsplit <= 0 || (a.nsplit - 1) * dattn_keys_per_split(kv_f32) >= a.max_ctx) return "qkv_dattn: key splits outside max_ctx";
-  if (!fa.ready || !fa.err || !fa.rms_w || fa.qkv_out != a.qkv) return "qkv_dattn: counters, norm weight and the shared qkv row are required";
-  QkvProj f{fa.x, fa.rms_w, fa.eps, fa.W, fa.bias, fa.K, fa.qkv_out, fa.fast_math, fa.ready, fa.err, fa.xcd_local, fa.cnt_stride > 0 ? fa.cnt_stride : 1, fa.dbg_nowait};
-  const dim3 grid(8 * (group * 8 + 16) + 8 * a.nsplit), block(DA_WAVES * 64);
-#define Q3A_QD(G)                                                                                                                  \
-  do {                                                                                                                             \
-    if (fa.K == 1024) {                                                                                                            \
-      if (kv_f32) hipLaunchKernelGGL((qkv_dattn_kernel<G, float, 2>), grid, block, 0, s, a, f);                                   \
-      else hipLaunchKernelGGL((qkv_dattn_kernel<G, uint16_t, 2>), grid, block, 0, s, a, f);                                       \
-    } else {                                                                                                                       \
-      if (kv_f32) hipLaunchKernelGGL((qkv_dattn_kernel<G, float, 4>), grid, block, 0, s, a, f);                                   \
-      else hipLaunchKernelGGL((qkv_dattn_kernel<G, uint16_t, 4>), grid, block, 0, s, a, f);                                       \
-    }                                                                                                                              \
-  } while (0)
-  if (group == 1) Q3A_QD(1);
-  else if (group == 2) Q3A_QD(2);
-  else Q3A_QD(4);
-#undef Q3A_QD
-  return nullptr;
-}
-
 // (S * n_kv -- the workgroups of the batched kernel -- from which the engine's batched decode step uses it is the knob
 // dattn_batched_min_wgs of kernels.h; below it the key-split kernel + merge keep more CUs busy.)
 
@@ -821,7 +650,6 @@ const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f
 #define Q3A_DAB(G)                                                                                          \
   do {                                                                                                      \
     if (kv_f32) hipLaunchKernelGGL((decode_attn_batched_kernel<G, float>), grid, block, 0, s, a);          \
-    else if (a.nsplit == -64) hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t, 64, 2>), grid, block, 0, s, a); \
     else hipLaunchKernelGGL((decode_attn_batched_kernel<G, uint16_t>), grid, block, 0, s, a);              \
   } while (0)
   if (group == 1) Q3A_DAB(1);
@@ -840,5 +668,4 @@ const char* launch_attn_combine(const float* pm, const float* pl, const float* p
   return nullptr;
 }
 
-#endif  // Q3A_BODY_ONLY
 }  // namespace q3a

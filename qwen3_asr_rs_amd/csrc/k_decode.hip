@@ -188,8 +188,6 @@ __global__ __launch_bounds__(1024) void argmax_finalize_kernel(FinalizeArgs a) {
     if (s == 0 && a.host_progress) __hip_atomic_store(a.host_progress, sc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
-  if (a.zero_words && s == 0)  // (one workgroup: the step's fused launches have completed; the next step's find zeroed counters)
-    for (int i = tid; i < a.n_zero_words; i += 1024) a.zero_words[i] = 0u;
   // RoPE row of the position the next decode step works at, at a fixed address: the attention kernels of that step
   // request it together with q/k/v instead of after a dependent load of pos
   if (a.rope_cur && tid < 128) a.rope_cur[(size_t)s * 128 + tid] = rope_v;

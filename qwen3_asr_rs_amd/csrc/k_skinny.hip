@@ -77,12 +77,8 @@ __device__ __forceinline__ float sq4(const float4& a) { return a.x * a.x + a.y *
 // the gate/up projection divisible in units of 8 columns instead of 16: at hidden 2048 (inter 6144: 384 pair tiles for 256 CUs --
 // a CU with two of them streams 2 x (128 KB of weights + the activations)) 256 workgroups x 3 half pairs give every CU 192 KB of
 // weights and ONE pass over the activations.  Same K slices, same reduction order per output element as the pair form.
-// PUB (k_fused.hip: the qkv projection inside the launch that also holds its consumers): the output is stored with agent-scope
-// (write-through) stores, every wave drains them and ONE lane then counts the workgroup in on `pub_cnt` (cdna_hip_programming.md
-// Guideline 16, producer side).  bid: the workgroup's tile index (the plain kernel passes blockIdx.x).
-template <bool SPLIT, int TILES, int SH, int XMODE, int UNR, bool WLDS, bool QS = false, bool PALIAS = false, bool HP = false, bool PUB = false>
-__device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bid, unsigned* pub_cnt = nullptr) {
-  static_assert(!PUB || (TILES == 1 && !HP && !QS), "published output: plain 16-row tiles");
+template <bool SPLIT, int TILES, int SH, int XMODE, int UNR, bool WLDS, bool QS = false, bool PALIAS = false, bool HP = false>
+__global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
   static_assert(!(SPLIT && XMODE >= 2), "the precise mode keeps fp32 activations");
   static_assert(!HP || (WLDS && PALIAS && !QS && !SPLIT), "half-pair tiles: LDS-staged weights, aliased partial tile");
   static_assert(!WLDS || UNR % 2 == 0, "the LDS image is made of 64-wide k columns");
@@ -108,11 +104,11 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bid, 
   if (TILES == 1 && !HP) { Q3A_ARG(a.next_w); Q3A_ARG(a.next_xw16f); Q3A_ARG(a.next_ss); }
   if (QS) Q3A_ARG(a.qs_halves);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  Q3A_STAMP_AT(a.stamp, bid, 0);  // entry
+  Q3A_STAMP_AT(a.stamp, blockIdx.x, 0);  // entry
   const int l15 = lane & 15, kc = lane >> 4;  // row / sequence inside the fragment, k-chunk (8 elements)
-  int n0 = bid * 16 * TILES, hsel = 0, part_row = bid;
+  int n0 = blockIdx.x * 16 * TILES, hsel = 0, part_row = blockIdx.x;
   if (QS) {  // block b: XCD b & 7; consecutive same-XCD blocks alternate the sequence half
-    const int xcd = bid & 7, j = bid >> 3;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     hsel = j % a.qs_halves;
     part_row = (j / a.qs_halves) * 8 + xcd;
     n0 = part_row * 8;
@@ -122,7 +118,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bid, 
   // their gate rows start at (c0 / 16) * 32 + c0 % 16 in the interleaved matrix, the up rows 16 further on.
   auto tile_row = [&](int t, int r16) -> int {
     if (!HP) return n0 + t * 16 + r16;
-    const int c0 = (bid * TILES + t) * 8;
+    const int c0 = (blockIdx.x * TILES + t) * 8;
     return ((c0 >> 4) << 5) + (c0 & 15) + (r16 >> 3) * 16 + (r16 & 7);
   };
   const int K = a.K;
@@ -242,9 +238,9 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bid, 
         w1[u] = *reinterpret_cast<const float4*>(nrow + ko + 4);
       }
     }
-    Q3A_STAMP_AT(a.stamp, bid, 1);  // every load of the pass requested
+    Q3A_STAMP_AT(a.stamp, blockIdx.x, 1);  // every load of the pass requested
     if (WLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA is not in the compiler's load bookkeeping
-    Q3A_STAMP_AT(a.stamp, bid, 2);  // (WLDS) weights landed
+    Q3A_STAMP_AT(a.stamp, blockIdx.x, 2);  // (WLDS) weights landed
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const bool live = kb + u < ks1;
@@ -282,7 +278,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bid, 
   }
   return;
 #endif
-  Q3A_STAMP_AT(a.stamp, bid, 3);  // MFMAs issued (their operands have arrived)
+  Q3A_STAMP_AT(a.stamp, blockIdx.x, 3);  // MFMAs issued (their operands have arrived)
   // D[row i][sequence j] of v_mfma_f32_16x16x32: j = lane&15, i = (lane>>4)*4 + r
 #pragma unroll
   for (int t = 0; t < TILES; ++t)
@@ -309,7 +305,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bid, 
     }
   }
   __syncthreads();
-  Q3A_STAMP_AT(a.stamp, bid, 4);  // partial tiles of all waves in LDS
+  Q3A_STAMP_AT(a.stamp, blockIdx.x, 4);  // partial tiles of all waves in LDS
   // ---- fixed-order reduction of the K-slices + epilogue: thread -> (row i, sequence s) ----
   // 16 rows x 32 sequences = 512 threads; 16 consecutive lanes own the 16 consecutive output columns of one sequence
   // (64-B runs; with the sequence as the fast index every lane hit its own line: 4 KB stride)
@@ -344,7 +340,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bid, 
     if (!live_s || i >= 8) return;
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-      const int c = (bid * TILES + t) * 8 + i;  // output column; its gate / up rows in the interleaved matrix:
+      const int c = (blockIdx.x * TILES + t) * 8 + i;  // output column; its gate / up rows in the interleaved matrix:
       const int gr = ((c >> 4) << 5) + (c & 15), ur = gr + 16;
       if (ur >= a.N) continue;
       float g = v[t], u = vu[t];
@@ -353,7 +349,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bid, 
       if (a.out16) a.out16[a.out16_frag ? skinny_frag_index(s, c) : (size_t)s * a.ldo + c] = (uint16_t)f32_to_bf16_bits(y);
       else a.out[(size_t)s * a.ldo + c] = y;
     }
-    Q3A_STAMP_AT(a.stamp, bid, 5);
+    Q3A_STAMP_AT(a.stamp, blockIdx.x, 5);
   } else if (TILES == 1) {
     const int n = n0 + i;
     const bool ok = live_s && n < a.N;
@@ -362,20 +358,14 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bid, 
       y = v[0];
       if (a.bias) y += ep_bias;
       if (a.mode == 1) y += ep_resid;
-      if constexpr (PUB) __hip_atomic_store(a.out + (size_t)s * a.ldo + n, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else a.out[(size_t)s * a.ldo + n] = y;
+      a.out[(size_t)s * a.ldo + n] = y;
     }
     if (a.mode == 1 && a.next_w) {  // hand the new residual row to the next GEMM pre-normalised (kernels.h)
       if (ok) a.next_xw16f[skinny_frag_index(s, n)] = (uint16_t)f32_to_bf16_bits(y * ep_nw);
       const float q = QS ? row8_sum(y * y) : row16_sum(y * y);  // this block's 16 (8) columns of sequence s
       if (i == 0 && live_s) a.next_ss[(size_t)part_row * 32 + s] = q;
     }
-    Q3A_STAMP_AT(a.stamp, bid, 5);  // epilogue stores issued
-    if constexpr (PUB) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores ...
-      __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ... then ONE lane counts the workgroup in
-    }
+    Q3A_STAMP_AT(a.stamp, blockIdx.x, 5);  // epilogue stores issued
   } else {  // rows n0..n0+15 = gate, n0+16..n0+31 = up of logical rows n0/2 .. n0/2+15
     if (!live_s || n0 + 16 + i >= a.N) return;
     float g = v[0], u = v[TILES - 1];
@@ -383,16 +373,10 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& a, const int bid, 
     const float y = silu_sel(g, a.fast_math != 0) * u;
     if (a.out16) a.out16[a.out16_frag ? skinny_frag_index(s, (n0 >> 1) + i) : (size_t)s * a.ldo + (n0 >> 1) + i] = (uint16_t)f32_to_bf16_bits(y);
     else a.out[(size_t)s * a.ldo + (n0 >> 1) + i] = y;
-    Q3A_STAMP_AT(a.stamp, bid, 5);
+    Q3A_STAMP_AT(a.stamp, blockIdx.x, 5);
   }
 }
 
-template <bool SPLIT, int TILES, int SH, int XMODE, int UNR, bool WLDS, bool QS = false, bool PALIAS = false, bool HP = false>
-__global__ __launch_bounds__(SK_WAVES * 64) void skinny_kernel(SkinnyArgs a) {
-  skinny_body<SPLIT, TILES, SH, XMODE, UNR, WLDS, QS, PALIAS, HP, false>(a, blockIdx.x);
-}
-
-#ifndef Q3A_BODY_ONLY  // (k_fused.hip includes this file for the device code above only)
 // dynamic LDS a kernel instance may use: the CU's 160 KiB minus its static arrays (part, ssp) and a 2 KiB margin
 constexpr size_t sk_dyn_lds_max(int tiles, int sh) {
   return 160 * 1024 - sizeof(float) * (SK_WAVES * tiles * sh * 16 * 17 + SK_WAVES * sh * 16) - 2048;
@@ -545,7 +529,4 @@ const char* launch_skinny(const SkinnyArgs& a, bool split, hipStream_t s) {
   return nullptr;
 }
 
-#else
-}  // namespace
-#endif  // Q3A_BODY_ONLY
 }  // namespace q3a

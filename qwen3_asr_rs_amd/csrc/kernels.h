@@ -259,22 +259,6 @@ struct DecodeAttnArgs {
 constexpr int DATTN_KEYS_PER_SPLIT_BF16 = Q3A_DATTN_SPLIT_KEYS, DATTN_KEYS_PER_SPLIT_F32 = 128;
 inline int dattn_keys_per_split(bool kv_f32) { return kv_f32 ? DATTN_KEYS_PER_SPLIT_F32 : DATTN_KEYS_PER_SPLIT_BF16; }
 const char* launch_decode_attn(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
-// ONE sequence, 8 kv heads: the qkv projection (RMSNorm fused, the GEMV's arithmetic) and the attention key splits as one launch
-// ordered by dispatch (k_dattn.hip qkv_dattn_kernel).  a.qkv == f.qkv_out.
-struct QkvFuseArgs {
-  const float* x; const float* rms_w; float eps;  // hidden row [K], input-norm weight
-  const uint16_t* W; const float* bias; int K;    // [(n_q + 2 n_kv) * 128][K] bf16, bias or null
-  float* qkv_out;
-  int fast_math;
-  unsigned* ready;                                 // 8 zeroed words private to this launch (re-zeroed before the next step)
-  unsigned* err;                                   // sticky count of waits that ran out
-  int xcd_local;                                   // (experiment) 1: hand-off through the XCD-local L2 (placement-dependent)
-  int cnt_stride, dbg_nowait;
-};
-const char* launch_qkv_dattn(const DecodeAttnArgs& a, const QkvFuseArgs& f, bool kv_f32, hipStream_t s);
-// Batched step: the qkv projection (pre-normalised skinny GEMM, mode 0, out = a.qkv) and the batched attention of the same S sequences
-// as one dispatch-ordered launch (k_fused.hip).  ready: 8 counters cnt_stride words apart, zeroed before the step.
-const char* launch_qkv_dattn_batched(const SkinnyArgs& q, const DecodeAttnArgs& a, int S, unsigned* ready, int cnt_stride, unsigned* err, hipStream_t s);
 // one workgroup per (sequence, kv head), online softmax over 128-key tiles, final output written directly (a.out / a.out16)
 const char* launch_decode_attn_batched(const DecodeAttnArgs& a, int S, bool kv_f32, hipStream_t s);
 // out[S][n_q*128] = merged partials (needed as its own launch only on the GEMM decode path)
@@ -305,8 +289,6 @@ struct FinalizeArgs {
   const float* cos_t; const float* sin_t;  // RoPE tables [max_pos][64]
   float* rope_cur;         // [S][128] (written): cos | sin row of the updated pos[s] (DecodeAttnArgs::rope_cur); nullable
   NextNormOut nn;          // pre-normalised copy of x_next for the first layer's qkv GEMM (skinny path)
-  unsigned* zero_words;    // arrival counters of the fused launches of a step (k_dattn.hip qkv_dattn_kernel): zeroed here, for the next step
-  int n_zero_words;
 };
 // block partials of logits [S][V] (GEMM decode path; the GEMV lm_head produces its own)
 const char* launch_argmax_partials(const float* logits, int V, int S, float* pval, int* pidx, int stride, int nblk,
