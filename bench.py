@@ -18,9 +18,19 @@ the native q3a_group_* path (one process, one host thread per GPU, RCCL called f
 that neither a crash nor a hang inside it can cost the line.
 
 What is inside the clock
-  value               PCM already resident in HBM when the clock starts (the task contract), generated ids fetched to the
-                      host inside the clock (q3a_run_resident + q3a_fetch_ids).
-  host_to_host.value  q3a_transcribe_batch: host PCM -> H2D -> hot path -> ids on the host (SURVEY.md section 8d window).
+  value               PCM already resident in HBM when the clock starts (the task contract: the PCIe-inclusive rate is never
+                      `value`), generated ids fetched to the host inside the clock (q3a_run_resident + q3a_fetch_ids).
+  value_host_to_host  = host_to_host.value: q3a_transcribe_batch_ptrs, host PCM -> H2D -> hot path -> ids on the host (SURVEY.md
+                      section 8d's window), same engine, same steps; host_to_host.varying_lengths: the same with utterance
+                      lengths that change every step (no reuse of the geometry tables).
+  precise_mode        the same workload with opts.precise = 1 (the mode whose greedy ids equal the fp32 oracle's exactly).
+  measured_peaks      q3a_measure_peaks on this GPU in this process: HBM read / copy / triad GB/s and the library's own
+                      256x256x64 bf16 GEMM on 8192^3 ("measure on the box"); every roofline object also
+                      carries frac_of_measured_hbm_read next to frac (of the 8 TB/s nominal peak).
+  extra[i].roofline   the same object for BASELINE configs[2] and configs[3] (dominant kernel of THAT workload in situ, its
+                      algorithmic bytes per launch, PMC traffic).
+  multi_gpu (N > 1)   rccl_ranks_seen (a device all-reduce of ones), per-rank value / ms_per_step, the arena broadcast's pack +
+                      wire time, wire-only time of a second device-to-device broadcast and its bit-identity.
 
 roofline (dominant kernel = the one with the largest share of kernel time IN THE TRACED RUN OF THIS WORKLOAD):
   avg_launch_us       per-launch average from `rocprofv3 --kernel-trace --stats` over graph-replayed steps of this very
