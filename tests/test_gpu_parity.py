@@ -57,6 +57,17 @@ def test_gemm16_against_device_reference(shape):
     assert r["err"] <= 2e-5 * max(r["ref_max"], 1.0), r
 
 
+def test_measured_peaks_are_plausible():
+    """q3a_measure_peaks (csrc/k_peaks.hip; SURVEY.md section 8d "measure on the box"): the numbers bench.py prints as the measured
+    denominators must be what an MI355X can do -- a read stream between a third of and the whole nominal 8 TB/s, copy and triad
+    below the read rate x 1.2, the library's own 8192^3 bf16 GEMM between 0.3 and 1.0 of the nominal 2.5 PFLOP/s."""
+    from qwen3_asr_rs_amd.engine import measure_peaks
+    pk = measure_peaks(0, 3)
+    assert 2600 < pk["hbm_read_GBps"] <= 8000, pk
+    assert 1500 < pk["hbm_copy_GBps"] <= 1.2 * pk["hbm_read_GBps"] and 1500 < pk["hbm_triad_GBps"] <= 1.2 * pk["hbm_read_GBps"], pk
+    assert 750 < pk["mfma_bf16_TFLOPs"] <= 2500 and pk["gemm"] == [8192, 8192, 8192] and pk["n_cu"] >= 64, pk
+
+
 def test_mel_reference_clips_and_hf_golden(tiny_dir):
     """Weight-free stage: real parity on the reference's own clips, also against the HF fixture."""
     eng = HipEngine(tiny_dir, 0)

@@ -238,6 +238,37 @@ def test_committed_bench_line_follows_the_contract():
     assert len(ex) == 2 and "batch=32" in ex[0]["workload"] and "1.7b" in ex[1]["workload"] and all(e["value"] > 0 for e in ex)
 
 
+def test_round6_bench_line_carries_the_driver_visible_evidence():
+    """profiles/r6_bench_final.json (round 6): the fields added this round are in the line a driver run produces --
+    per-leg roofline objects for BASELINE configs[2] / configs[3], the measured denominators, the precise-mode throughput, the
+    host-to-host window at the top level -- and they are internally consistent."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    j = json.load(open(os.path.join(root, "profiles", "r6_bench_final.json")))
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["config"]["timed_window"].startswith("PCM resident")   # the contract's `value`
+    assert j["value_host_to_host"] == j["host_to_host"]["value"] and 0 < j["value_host_to_host"] <= 1.02 * j["value"]
+    vl = j["host_to_host"]["varying_lengths"]
+    assert 0 < vl["value"] <= 1.02 * j["value"] and vl["ms_per_step"] > 0
+    pk = j["measured_peaks"]
+    assert 2600 < pk["hbm_read_GBps"] <= 8000 and 750 < pk["mfma_bf16_TFLOPs"] <= 2500 and pk["gemm"] == [8192, 8192, 8192]
+    r = j["roofline"]
+    assert abs(r["frac_of_measured_hbm_read"] - r["achieved"] / pk["hbm_read_GBps"]) < 1e-3 and r["frac_of_measured_hbm_read"] > r["frac"]
+    assert len(r["avg_launch_us_of_the_child_runs"]) == 3 and r["traffic"] >= 0.95 * r["bytes_per_launch"]
+    pm = j["precise_mode"]
+    assert 0 < pm["value"] < j["value"] and abs(pm["value"] * pm["ms_per_step"] / 1e3 - 30.0) < 0.5
+    c = j["cpu_baseline"]
+    assert c["cores_physical"] >= c["cores"] >= 1 and c["cores_logical"] >= c["cores_physical"]
+    ex = j["extra"]
+    assert len(ex) == 2 and "batch=32" in ex[0]["workload"] and "1.7b" in ex[1]["workload"]
+    for e, kern in zip(ex, ("decode_attn_batched_kernel", "skinny_kernel")):
+        rr = e["roofline"]
+        assert rr["kernel"].startswith(kern) and rr["bound"] == "hbm" and "rocprofv3" in rr["avg_launch_us_source"]
+        assert abs(rr["achieved"] - rr["bytes_per_launch"] / rr["avg_launch_us"] / 1e3) < 1.0 and abs(rr["frac"] - rr["achieved"] / rr["peak"]) < 1e-3
+        assert 0.9 * rr["bytes_per_launch"] <= rr["traffic"] <= 1.2 * rr["bytes_per_launch"] and "pmc" in rr["traffic_source"]
+        assert abs(rr["launches_per_token"] - 28) < 0.5 and 0 < rr["decode_stage"]["frac"] < rr["frac"]
+        assert e["host_to_host"]["value"] <= 1.02 * e["value"]
+
+
 def test_bench_kernel_trace_leaves_the_warmup_pass_out(tmp_path, monkeypatch):
     """bench.kernel_trace: per kernel, the dispatches of the warm-up passes (the first warmup / (warmup + steps) by start time) are
     dropped from the in-situ statistics, as the bench's own timed region drops its warm-up steps (no rocprofv3, no GPU: a rocpd-shaped
