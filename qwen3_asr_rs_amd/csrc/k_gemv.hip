@@ -255,8 +255,14 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int g, const in
 // IN FRONT of the weight stream.  Loads return in order: behind the weights (MF = 0) the merge starts when the last weight chunk
 // has landed and its exp / scale / LDS round trip / barrier sit exposed between the stream and the FMAs; in front, the partials are
 // back after one L2 round trip and the merged vector is in LDS while the weights are still in flight.
-template <int PR, int KI, bool RMS, bool ATTN, int MF = 0>
+// XL (round 6; !ATTN; used for the norm-fused projections at K <= 1024): x (and the norm weight) are fetched ONCE per workgroup -- KI / 2 16-byte loads per lane instead of
+// 2 KI (4 KI with the norm weight) -- and handed to the four waves through LDS: every wave needs the whole vector, and in the
+// register form each of them pulls it through the CU's texture-address path again (two thirds of a qkv workgroup's load
+// instructions were x and norm-weight re-reads).  Same values, same arithmetic.
+template <int PR, int KI, bool RMS, bool ATTN, int MF = 0, bool XL = false>
 __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
+  static_assert(!XL || !ATTN, "the merged attention vector already goes through LDS");
+  __shared__ __attribute__((aligned(16))) float xl_x[XL ? KI * 512 : 4], xl_w[(XL && RMS) ? KI * 512 : 4];
   __shared__ float am_v[4][1];
   __shared__ int am_i[4][1];
   __shared__ __attribute__((aligned(16))) float x_s[ATTN ? KI * 512 : 4];  // only the attention merge goes through LDS
@@ -277,8 +283,19 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   }
   float4 xr[KI][2], nr[RMS ? KI : 1][2];
   uint4 wq[KI][PR];
+  constexpr int XLN = (KI + 1) / 2;  // 16-byte pieces of x per lane in the XL form (256 lanes x 4 floats = 1024 columns per round)
+  float4 xl_rx[XL ? XLN : 1], xl_rw[(XL && RMS) ? XLN : 1];
   auto request_x = [&]() {  // L2 hits
     if (ATTN) return;
+    if constexpr (XL) {
+#pragma unroll
+      for (int j = 0; j < XLN; ++j) {
+        const int k = (tid + j * 256) * 4, kc = k < K ? k : 0;
+        xl_rx[j] = *reinterpret_cast<const float4*>(a.x + kc);
+        if (RMS) xl_rw[j] = *reinterpret_cast<const float4*>(a.rms_w + kc);
+      }
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < KI; ++it) {
       xr[it][0] = *reinterpret_cast<const float4*>(a.x + kk[it]);
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);  // the partials' requests stay in front of the weight stream
   }
-  if (RMS) { request_x(); request_w(); } else { request_w(); request_x(); }
+  if (RMS || XL) { request_x(); request_w(); } else { request_w(); request_x(); }
   // epilogue operands (bias, residual) ride behind the stream instead of costing an L2 round trip at the very end
   float bv[PR], rv[PR];
 #pragma unroll
@@ -373,6 +390,26 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
     for (int it = 0; it < KI; ++it) {
       xr[it][0] = *reinterpret_cast<const float4*>(x_s + kk[it]);
       xr[it][1] = *reinterpret_cast<const float4*>(x_s + kk[it] + 4);
+    }
+  }
+  if constexpr (XL) {  // hand the vector to the four waves (the weights are still in flight)
+#pragma unroll
+    for (int j = 0; j < XLN; ++j) {
+      const int k = (tid + j * 256) * 4;
+      if (k < KI * 512) {
+        *reinterpret_cast<float4*>(xl_x + k) = xl_rx[j];
+        if (RMS) *reinterpret_cast<float4*>(xl_w + k) = xl_rw[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < KI; ++it) {
+      xr[it][0] = *reinterpret_cast<const float4*>(xl_x + kk[it]);
+      xr[it][1] = *reinterpret_cast<const float4*>(xl_x + kk[it] + 4);
+      if (RMS) {
+        nr[it][0] = *reinterpret_cast<const float4*>(xl_w + kk[it]);
+        nr[it][1] = *reinterpret_cast<const float4*>(xl_w + kk[it] + 4);
+      }
     }
   }
   Q3A_STAMP_AT(a.stamp, blockIdx.x, 2);  // (ATTN: merged vector in LDS)
@@ -534,8 +571,18 @@ void launch1k(const GemvArgs& a, hipStream_t s) {
   if (a.attn_po && KI <= 4 && a.attn_nsplit <= 4) hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, true, 4>), grid, block, 0, s, a);
   else if (a.attn_po && KI <= 4 && a.attn_nsplit <= 8) hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, true, 8>), grid, block, 0, s, a);
   else if (a.attn_po) hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, true>), grid, block, 0, s, a);
-  else if (a.rms_w) hipLaunchKernelGGL((gemv1_kernel<PR, KI, true, false>), grid, block, 0, s, a);
-  else hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, false>), grid, block, 0, s, a);
+  else if (a.rms_w) {
+    // Norm-fused projections at K <= 1024 (qkv, gate / up at hidden 1024): x and the norm weight once per workgroup through LDS
+    // (round 6: 609.7 -> 595.1 us per step at 0.6B, ids identical; profiles/r6_ab_gemv_x_lds.txt).  Not where it was measured to
+    // lose: K = 2048 (+18 %: 32 KiB of LDS per workgroup halves the residency of the 1536-workgroup gate / up launch), the down
+    // projection (+4 %: x in front of the weights delays them), the lm_head (+1.3 %: a barrier in each of 9496 workgroups).
+    if constexpr (KI == 2) {
+      if (a.mode != 3) { hipLaunchKernelGGL((gemv1_kernel<PR, KI, true, false, 0, true>), grid, block, 0, s, a); return; }
+    }
+    hipLaunchKernelGGL((gemv1_kernel<PR, KI, true, false>), grid, block, 0, s, a);
+  } else {
+    hipLaunchKernelGGL((gemv1_kernel<PR, KI, false, false>), grid, block, 0, s, a);
+  }
 }
 template <int PR>
 void launch1(const GemvArgs& a, hipStream_t s) {
