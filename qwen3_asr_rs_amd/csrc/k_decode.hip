@@ -147,16 +147,33 @@ __global__ __launch_bounds__(1024) void argmax_finalize_kernel(FinalizeArgs a) {
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* pv = a.part_val + (size_t)s * a.part_stride;
   const int* pi = a.part_idx + (size_t)s * a.part_stride;
-  // everything that does not depend on the chosen token is requested up front, next to the partial maxima: the
-  // sequence's counters and the RoPE row of its next position (one memory round trip instead of three in a chain)
+  // Everything that does not depend on the chosen token is requested up front, in ONE batch: the sequence's counters, the partial
+  // maxima (up to FIN_PRE per lane, clamped addresses -- round 6: the plain loop `for (i = tid; i < n_part; i += 1024)` compiled to
+  // two loads and a vmcnt(0) per iteration, ten dependent L2 round trips for the 9496 partials of the one-sequence lm_head) and,
+  // behind `pos`, the RoPE row of the next position.
+  constexpr int FIN_PRE = 10;  // 10 240 partials (vocabulary 151 936 in 16-row blocks: 9496); more are folded by the loop below
   const int np = a.pos[s] + a.advance;
   const int sc = a.step_count[s];
   const int was_done = a.done[s];
+  float pre_v[FIN_PRE];
+  int pre_i[FIN_PRE];
+#pragma unroll
+  for (int j = 0; j < FIN_PRE; ++j) {
+    const int i = tid + j * 1024, ic = i < a.n_part ? i : a.n_part - 1;
+    pre_v[j] = pv[ic];
+    pre_i[j] = pi[ic];
+  }
   float rope_v = 0.f;
   if (a.rope_cur && tid < 128) rope_v = tid < 64 ? a.cos_t[(size_t)np * 64 + tid] : a.sin_t[(size_t)np * 64 + tid - 64];
   float best = -INFINITY;
   int idx = 0x7fffffff;
-  for (int i = tid; i < a.n_part; i += 1024) {
+#pragma unroll
+  for (int j = 0; j < FIN_PRE; ++j) {
+    const float v = tid + j * 1024 < a.n_part ? pre_v[j] : -INFINITY;
+    const int ix = pre_i[j];
+    if (v > best || (v == best && ix < idx)) { best = v; idx = ix; }
+  }
+  for (int i = tid + FIN_PRE * 1024; i < a.n_part; i += 1024) {
     const float v = pv[i];
     const int ix = pi[i];
     if (v > best || (v == best && ix < idx)) { best = v; idx = ix; }
