@@ -325,12 +325,22 @@ __global__ __launch_bounds__(256) void gemv1_kernel(GemvArgs a) {
   if constexpr (ATTN && MF > 0) {
     const int kc = mg_k < K ? mg_k : 0;
     const int h = kc >> 7, d = kc & 127, ns = a.attn_nsplit, base = h * ns;
+    // A head's statistics are ns consecutive floats: 16-byte loads (4-byte aligned; entries past the head's own belong to the next
+    // head or to the allocation's 256-byte rounding and are voided) instead of one 4-byte load per split -- and NO branch around
+    // loads: a uniform `if` whose arms load made hipcc wait at the join before requesting anything else (tests/test_isa_hazards.py).
+    typedef float __attribute__((ext_vector_type(4), aligned(4))) f4u_t;
+#pragma unroll
+    for (int j = 0; j < MCH; j += 4) {
+      const f4u_t m4 = *reinterpret_cast<const f4u_t*>(a.attn_pm + base + j), l4 = *reinterpret_cast<const f4u_t*>(a.attn_pl + base + j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mg_m[j + e] = j + e < ns ? m4[e] : -INFINITY;
+        mg_l[j + e] = l4[e];
+      }
+    }
 #pragma unroll
     for (int j = 0; j < MCH; ++j) {
-      const int spc = j < ns ? j : ns - 1;  // clamp the address, void the statistics
-      mg_m[j] = a.attn_pm[base + spc];
-      mg_l[j] = a.attn_pl[base + spc];
-      if (j >= ns) mg_m[j] = -INFINITY;
+      const int spc = j < ns ? j : ns - 1;
       mg_o0[j] = *reinterpret_cast<const float4*>(a.attn_po + (size_t)(base + spc) * 128 + d);
       mg_o1[j] = *reinterpret_cast<const float4*>(a.attn_po + (size_t)(base + spc) * 128 + d + 4);
     }
