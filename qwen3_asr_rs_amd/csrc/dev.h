@@ -158,6 +158,14 @@ __device__ __forceinline__ float rstd_of(float mean_sq_plus_eps, bool fast) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float silu_sel(float x, bool fast) { return (Q3A_FAST_EPILOGUE && fast) ? silu_fast(x) : silu_f(x); }
 
+// The lane id from a statement hipcc may not merge with an earlier one: what is derived from it is recomputed where it is used instead
+// of living in registers across a loop that does not need it (the epilogue constants and row-pointer inputs of k_gemm256.hip's walk)
+__device__ __forceinline__ int lane_id_fresh() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 __device__ __forceinline__ float lane_bcast(float v, int lane_uniform) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
 }

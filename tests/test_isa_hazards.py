@@ -64,7 +64,7 @@ def test_batched_requests_stay_batched_in_the_device_code():
         assert len(name) == 1, (pattern, name)
         return max([int(n or 1) for n in re.findall(r"\bG(?:x(\d+))?\b", ks[name[0]])] or [0])
 
-    assert longest_load_run(r"gemm256_kernelILb0ENS0_9DenseA256ELb0EEE") >= 30      # 32 residual rows (hipcc may move one or two)
+    assert longest_load_run(r"gemm256_kernelILb0ENS0_9DenseA256ELb0EEE") >= 15      # the residual rows of two 32-row passes (16) back to back, twice per tile (round 5: all 32 at once, two 64-row passes)
     assert longest_load_run(r"gemv1_kernelILi1ELi4ELb0ELb1ELi0ELb0EEE") >= 26       # chunked merge (> 8 splits): 4 x (m, l, o0, o1) + ... in one batch
     assert longest_load_run(r"gemv1_kernelILi1ELi4ELb0ELb1ELi4ELb0EEE") >= 14       # <= 4 splits: 2 statistics + 8 partial-row loads, then the 4 weight chunks, no wait between
     assert longest_load_run(r"gemv1_kernelILi1ELi4ELb0ELb1ELi8ELb0EEE") >= 24       # <= 8 splits: 4 + 16 + 4
