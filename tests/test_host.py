@@ -392,9 +392,12 @@ def test_mfma_table_shapes_and_launch_matching():
     mt = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mt)
     shp = mt.shapes("0.6b", 32)
-    grids = {}
+    grids, launched = {}, {}
     for x in shp:
-        grids.setdefault(x["label"], x["grid"])
+        grids.setdefault(x["label"], x["tiles"])
+        launched.setdefault(x["label"], x["grid"])
+    # round 6: the persistent walk launches min(tiles, 256 CUs) workgroups
+    assert launched["conv2 implicit GEMM"] == 256 and launched["enc fc1 (GELU)"] == 256 and launched["enc out (+residual)"] == 196 and launched["dec down (+residual)"] == 204
     assert grids["conv2 implicit GEMM"] == 6000 and grids["conv3 implicit GEMM"] == 1560 and grids["enc qkv"] == 506
     assert grids["enc fc1 (GELU)"] == 686 and grids["enc out (+residual)"] == 196 and grids["enc fc2 (+residual)"] == 196
     assert grids["dec qkv + QK-norm/RoPE/KV epilogue"] == 768 and grids["dec gate/up (SwiGLU)"] == 1224 and grids["dec down (+residual)"] == 204

@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = 2500.0
+CUS = 256  # MI355X
 BM = BN = 256
 BK = 64
 
@@ -78,7 +79,9 @@ def shapes(preset, B, seconds=30.0):
         Kp = -(-K // BK) * BK
         if (-(-M // BM)) * tn < 128:
             continue  # gemm256_eligible(): fewer than gemm256_min_tiles (128) tiles run on the small-tile kernel instead
-        out.append(dict(label=label, ksub=ksub, M=M, Mk=Mk, N=N, K=K, grid=tm * tn, alg=2.0 * Mk * N * K, padded=2.0 * tm * BM * tn * BN * Kp))
+        # grid: round 6's persistent walk launches min(tiles, CUs) workgroups (Q3A_GEMM256_PERSIST=0: one per tile)
+        grid = tm * tn if os.environ.get("Q3A_GEMM256_PERSIST", "1") == "0" else min(tm * tn, CUS)
+        out.append(dict(label=label, ksub=ksub, M=M, Mk=Mk, N=N, K=K, tiles=tm * tn, grid=grid, alg=2.0 * Mk * N * K, padded=2.0 * tm * BM * tn * BN * Kp))
     return out
 
 
@@ -180,7 +183,7 @@ def main():
             wsum += util * s["alg"] * n_per_pass
             wflops += s["alg"] * n_per_pass
         f = lambda v, fmt: (fmt % v) if v is not None else "-"
-        print(f"{lab:38s} {('%d x %d x %d' % (s['Mk'], s['N'], s['K'])):26s} {s['grid']:6d} {f(util, '%.3f'):>9s} {f(pdur, '%.1f'):>8s} {f(sclk, '%.2f'):>9s} "
+        print(f"{lab:38s} {('%d x %d x %d' % (s['Mk'], s['N'], s['K'])):26s} {s['tiles']:6d} {f(util, '%.3f'):>9s} {f(pdur, '%.1f'):>8s} {f(sclk, '%.2f'):>9s} "
               f"{f(tdur, '%.1f'):>9s} {f(tf, '%.0f'):>9s} {f(tf / PEAK_TFLOPS if tf else None, '%.3f'):>9s} {s['padded'] / s['alg']:10.3f} {s['alg'] * n_per_pass / 1e9:10.0f}")
     if wflops:
         print(f"# FLOP-weighted MfmaUtil over these launches: {wsum / wflops:.3f}")
