@@ -109,7 +109,6 @@ Knobs& knobs() {
     env("Q3A_DATTN_BATCHED_MIN_WGS", k.dattn_batched_min_wgs);
     env("Q3A_DECODE_GROUP", k.decode_group_size);
     env("Q3A_DECODE_PARALLEL", k.decode_parallel_groups);
-    env("Q3A_DECODE_STEPS_PER_GRAPH", k.decode_steps_per_graph);
     env("Q3A_FUSE_QKROPE", k.fuse_qkrope);
     env("Q3A_SKINNY_Q", k.skinny_q);
     env("Q3A_EOS_RUN_AHEAD", k.eos_run_ahead);
@@ -177,7 +176,7 @@ struct q3a_engine {
   // ---- graph ----
   // instantiated decode-step graphs by signature (make_graph_sig): a batch shape met before -- or the same batch at a key-split
   // count met before -- replays without a new capture; oldest entry dropped beyond kGraphCacheMax
-  static constexpr size_t kGraphCacheMax = 24;
+  static constexpr size_t kGraphCacheMax = 16;
   std::vector<std::pair<std::string, hipGraphExec_t>> graph_cache;
   // Key splits the one-sequence decode attention launches (k_dattn.hip decode_attn_kernel: one workgroup per kv head and
   // 128-key split).  Sized by what the caches HOLD, not by their capacity: pos_hi_ = longest prompt + decode steps enqueued
@@ -1084,9 +1083,8 @@ struct q3a_engine {
     const int smallest = ng == 1 ? B : std::min(gsize, B - (ng - 1) * gsize);
     return smallest * d.n_kv < k_dattn_batched_min_wgs;
   }
-  // `steps` consecutive decode steps as ONE graph (they must share the key-split count: decode_steps checks)
-  hipGraphExec_t graph_for_step(int steps = 1) {
-    const std::string sig = make_graph_sig() + "x" + std::to_string(steps);
+  hipGraphExec_t graph_for_step() {
+    const std::string sig = make_graph_sig();
     for (size_t i = 0; i < graph_cache.size(); ++i)
       if (graph_cache[i].first == sig) {  // LRU: a hit moves the entry to the back, eviction takes the front
         if (i + 1 != graph_cache.size()) std::rotate(graph_cache.begin() + i, graph_cache.begin() + i + 1, graph_cache.end());
@@ -1096,7 +1094,7 @@ struct q3a_engine {
     hipGraphExec_t exec = nullptr;
     HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     try {
-      for (int k = 0; k < steps; ++k) enqueue_decode_step();
+      enqueue_decode_step();
     } catch (...) {
       hipGraph_t tmp = nullptr;
       (void)hipStreamEndCapture(stream, &tmp);
@@ -1135,27 +1133,16 @@ struct q3a_engine {
     if (n <= 0) return;
     const bool eager = !opts.use_graph || prof;
     const int kps = dattn_keys_per_split(kv_f32());
-    // Several steps per graph when the caller asks for several (the fixed-length mode; the natural-EOS loop asks for one at a
-    // time).  The seam between two graph launches costs the device ~8 us where a kernel boundary inside a graph costs ~1.4
-    // (profiles/r6_gap_stats_b1.txt: argmax_finalize -> the next step's first GEMV, median 8.4 us) -- 1.3 % of a one-clip step.  A
-    // step reads its position from device memory, so replaying the captured launches k times IS k steps; the only host-side
-    // per-step state is the live key-split count, so a chunk ends where that count changes.  Chunk sizes are powers of two
-    // (<= decode_steps_per_graph): at most log2 + 1 graphs per signature.
-    const int per_graph = std::max(1, knobs().decode_steps_per_graph.load());
-    for (int i = 0; i < n;) {
+    // (Round 6 measured several steps per graph for the fixed-length mode -- a kernel trace shows 8.4 us between a step's finalize and
+    // the next step's first GEMV against ~1.4 us inside a graph -- and un-traced it does not pay: one clip 592 -> 590 / 592 / 599 /
+    // 607 / 610 us per step at 2 / 4 / 8 / 16 / 32 steps per graph, 32 clips 1131 -> 1126: the seam is the tracer's.  Code at commit
+    // 03b3a8b, profiles/r6_ab_decode_steps_per_graph.txt.)
+    for (int i = 0; i < n; ++i) {
       // this step feeds the token at position <= pos_hi_ and attends keys 0 .. pos_hi_
-      const bool splits = uses_key_splits();
-      live_nsplit_ = splits ? std::min(attn_nsplit, pos_hi_ / kps + 1) : attn_nsplit;
-      int run = 1;
-      if (!eager && per_graph > 1) {
-        const int same = (splits && live_nsplit_ < attn_nsplit) ? live_nsplit_ * kps - pos_hi_ : n;  // steps from here with this split count
-        const int cap = std::min(std::min(n - i, same), per_graph);
-        while (run * 2 <= cap) run *= 2;
-      }
+      live_nsplit_ = uses_key_splits() ? std::min(attn_nsplit, pos_hi_ / kps + 1) : attn_nsplit;
       if (eager) enqueue_decode_step();
-      else HIPCHK(hipGraphLaunch(graph_for_step(run), stream));
-      pos_hi_ += run;
-      i += run;
+      else HIPCHK(hipGraphLaunch(graph_for_step(), stream));
+      ++pos_hi_;
     }
     if (eager) HIPCHK(hipGetLastError());
   }
@@ -1702,7 +1689,6 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   Knobs& kn = knobs();
   if (strcmp(key, "gemm256_min_tiles") == 0) { kn.gemm256_min_tiles = value; return 0; }
   if (strcmp(key, "gemm256_persist") == 0) { kn.gemm256_persist = value; return 0; }
-  if (strcmp(key, "decode_steps_per_graph") == 0) { kn.decode_steps_per_graph = value; return 0; }
   if (strcmp(key, "dattn_batched_min_wgs") == 0) { kn.dattn_batched_min_wgs = value; return 0; }
   if (strcmp(key, "decode_group_size") == 0) { kn.decode_group_size = value; return 0; }
   if (strcmp(key, "decode_parallel_groups") == 0) { kn.decode_parallel_groups = value; return 0; }

@@ -61,7 +61,6 @@ struct Knobs {
   std::atomic<int> dattn_batched_min_wgs{128};  // Q3A_DATTN_BATCHED_MIN_WGS: S * n_kv from which launch_decode_attn_batched is used
   std::atomic<int> decode_group_size{0};        // Q3A_DECODE_GROUP: sequences per group of the batched decode step (0 = 32)
   std::atomic<int> decode_parallel_groups{1};   // Q3A_DECODE_PARALLEL: groups as parallel stream / graph branches
-  std::atomic<int> decode_steps_per_graph{8};   // Q3A_DECODE_STEPS_PER_GRAPH: decode steps captured per hipGraph when the caller asks for several at once (fixed-length mode); 1 = one graph launch per step
   std::atomic<int> fuse_qkrope{1};              // Q3A_FUSE_QKROPE: QK-norm + RoPE + cache append as the qkv GEMM's epilogue
   std::atomic<int> skinny_q{1};                 // Q3A_SKINNY_Q: quarter workgroups for the o / down projections
   std::atomic<int> eos_run_ahead{1};            // Q3A_EOS_RUN_AHEAD: decode steps kept enqueued ahead of the device in natural-EOS mode.  1: exactly the steps needed are executed; paired with a fixed-N run of the same engine (profiles/r5_eos_run_ahead_ab.txt, two processes): 1 costs +0.03 / +1.24 ms per 100 tokens, 2 costs +2.07 / +1.86 ms (one wasted step + the same launch latency), 3 +1.3 / +1.2, 4 +3.3 / +3.1
