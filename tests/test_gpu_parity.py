@@ -343,6 +343,41 @@ def test_gate_up_skinny_gemm_forms_are_bit_identical():
         lib.q3a_debug_set(b"skinny_glu_hp3", 1)
 
 
+def test_gemm256_persistent_walk_is_bit_identical_to_one_workgroup_per_tile():
+    """k_gemm256.hip, round 6: a launch of more tiles than CUs is min(tiles, CUs) workgroups that WALK the tiles, the next tile's first
+    K tile arriving under the epilogue (staging halved to 8 KiB per wave, four 32-row passes); knob gemm256_persist = 0 launches one
+    workgroup per tile.  Same K order and the same epilogue arithmetic, so everything downstream must agree BIT FOR BIT: 32 x 30 s
+    clips at the 0.6B dimensions put every epilogue kind through tile seams -- conv2 / conv3 (implicit-GEMM loader, 6000 / 1560 tiles),
+    encoder qkv / fc1 (bf16, GELU; 506 / 686), decoder qkv with the QK-norm + RoPE + cache-append epilogue (768: the KV cache the
+    decode steps read), gate / up (SwiGLU, 1224); the 196 / 204-tile residual shapes run one round either way.  Compared: audio
+    embeddings, prefill logits, two decode steps' logits (they read the cache rows the fused epilogue wrote)."""
+    from qwen3_asr_rs_amd import _lib
+    from qwen3_asr_rs_amd.distributed import pack_arena_host
+    lib = _lib.load()
+    d = synthetic.write_checkpoint("/tmp/q3a_ckpt_0p6b", "0.6b", seed=0)
+    clips = [synthetic.synthetic_clip(300 + i, 30.0) for i in range(32)]
+    arena = pack_arena_host(d).to("cuda:0")
+    torch.cuda.synchronize()
+    got = {}
+    try:
+        for persist in (0, 1):
+            assert lib.q3a_debug_set(b"gemm256_persist", persist) == 0
+            eng = HipEngine(d, 0, max_new_tokens=8, device_arena=(arena.data_ptr(), arena.numel()))
+            eng.mel(clips)
+            emb = np.concatenate([e.ravel() for e in eng.encode()])
+            prompts = [HipEngine.build_prompt(eng.num_audio_tokens(len(c))) for c in clips]
+            logits, _ = eng.prefill(prompts)
+            eng.set_next_tokens([11 + 3 * i for i in range(32)])
+            lg1, _, _ = eng.decode_step()
+            lg2, nx, _ = eng.decode_step()
+            got[persist] = (emb, logits.copy(), lg1.copy(), lg2.copy(), nx.copy())
+            eng.close()
+    finally:
+        lib.q3a_debug_set(b"gemm256_persist", 1)
+    for a, b in zip(got[0], got[1]):
+        assert np.isfinite(a).all() and np.array_equal(a, b), float(np.abs(a.astype(np.float64) - b).max())
+
+
 def test_mfma_attention_matches_valu_attention(tiny_dir):
     """Default mode: the MFMA flash-attention kernels against the fp32 VALU kernels on the same inputs
     (two windows in the encoder, ragged causal prefill)."""
