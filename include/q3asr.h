@@ -272,7 +272,8 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *   "gemm256_min_tiles"  minimum number of 256x256 output tiles for which the bf16 GEMM dispatches to the 8-wave
  *                        counted-vmcnt kernel (k_gemm256.hip): 0 = whenever the shape allows, a huge value = never.
  *   "gemm256_persist"    1 (default): a gemm256 launch is min(tiles, CUs) workgroups that walk the tiles of their XCD's chunk, the next
- *                        tile's first K tile arriving under the epilogue; 0: one workgroup per tile.  Same arithmetic: bit-identical.
+ *                        tile's first K tile arriving under the epilogue; 0: one workgroup per tile; n > 1: a walk of exactly n workgroups (tests).
+ *                        Same arithmetic: bit-identical.
  *   "dattn_batched_min_wgs"  sequences x kv heads of a decode group from which the batched decode step uses the
  *                        one-workgroup-per-(sequence, kv head) attention kernel (k_dattn.hip) instead of key splits + merge.
  *   "decode_group_size"  sequences per group of the batched decode step (1..32; 0 = 32), taken at the next prefill.

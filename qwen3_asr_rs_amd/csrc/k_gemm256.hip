@@ -158,11 +158,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
   const int tiles_m = (M + G_BM - 1) / G_BM, tiles_n = (N + G_BN - 1) / G_BN;
   const int nwg = tiles_m * tiles_n;
   // this XCD's chunk of the tile order (the bijective remap of the one-tile-per-workgroup form) and this workgroup's walk through it
-  const int G = gridDim.x, xcd = blockIdx.x & 7;
-  const int xq = nwg >> 3, xr = nwg & 7;
+  // (a grid of fewer than 8 workgroups -- only tests launch one -- cuts the tile order into as many chunks as it has workgroups)
+  const int G = gridDim.x;
+  int xcd, xq, xr, wpx, tj;  // chunk of this workgroup, chunk sizes (xq or xq + 1 tiles), workgroups of the launch on this chunk, index inside the chunk
+  if (G >= 8) {
+    xcd = blockIdx.x & 7; xq = nwg >> 3; xr = nwg & 7;
+    wpx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);
+    tj = blockIdx.x >> 3;
+  } else {
+    xcd = blockIdx.x; xq = nwg / G; xr = nwg % G;
+    wpx = 1;
+    tj = 0;
+  }
   const int x_first = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq, x_cnt = xq + (xcd < xr ? 1 : 0);
-  const int wpx = (G >> 3) + (xcd < (G & 7) ? 1 : 0);  // workgroups of this launch on this XCD
-  int tj = blockIdx.x >> 3;                             // index inside the chunk
   if (tj >= x_cnt) return;                              // (G <= tiles: never)
   int bid = x_first + tj;
   Q3A_STAMP_AT(ep.stamp, bid, 0);  // entry
@@ -772,8 +780,11 @@ template <bool GLU, class ALoader, bool ROPE = false>
 void launch256(const ALoader& A, const uint16_t* W, const uint16_t* zero, int M, int N, int K, const GemmEpilogue& ep, hipStream_t s,
                const RopeKvArgs& rk = RopeKvArgs{}) {
   const int tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
-  const int cus = device_cus();
-  const int grid = knobs().gemm256_persist.load(std::memory_order_relaxed) != 0 && tiles > cus ? cus : tiles;
+  // gemm256_persist: 0 = one workgroup per tile, 1 = walk with one workgroup per CU, n > 1 = walk with exactly n workgroups (tests:
+  // grids that are not a multiple of 8, fewer workgroups than XCDs, one workgroup walking everything)
+  const int pk = knobs().gemm256_persist.load(std::memory_order_relaxed);
+  const int cus = pk > 1 ? pk : device_cus();
+  const int grid = pk != 0 && tiles > cus ? cus : tiles;
   hipLaunchKernelGGL((gemm256_kernel<GLU, ALoader, ROPE>), dim3(grid), dim3(512), 0, s, A, W, zero, M, N, K, ep, rk);
 }
 

@@ -343,6 +343,27 @@ def test_gate_up_skinny_gemm_forms_are_bit_identical():
         lib.q3a_debug_set(b"skinny_glu_hp3", 1)
 
 
+@pytest.mark.parametrize("wgs", [2, 5, 13, 250])
+def test_gemm256_walk_with_odd_workgroup_counts(wgs):
+    """The walk's XCD chunk arithmetic (k_gemm256.hip: workgroup b walks tiles loc, loc + w, ... of the chunk of XCD b % 8) on grids
+    that are not what an MI355X gives it: two workgroups walking everything, fewer workgroups than XCDs, counts that are not multiples
+    of 8 -- against the fp64-accumulating device reference, on shapes with ragged edges, two K tiles (the seam variants are the whole
+    K loop) and an odd K-tile count (the staging half flips per tile)."""
+    from qwen3_asr_rs_amd import _lib
+    from qwen3_asr_rs_amd.engine import selftest_gemm16
+    lib = _lib.load()
+    try:
+        assert lib.q3a_debug_set(b"gemm256_min_tiles", 0) == 0
+        assert lib.q3a_debug_set(b"gemm256_persist", wgs) == 0
+        for shape in [(1300, 1030, 128), (2049, 1024, 448), (3000, 2688, 896)] if wgs > 5 else [(1300, 1030, 128), (1000, 770, 448)]:
+            for _ in range(2):
+                r = selftest_gemm16(*shape)
+                assert r["err"] <= 2e-5 * max(r["ref_max"], 1.0), (wgs, shape, r)
+    finally:
+        lib.q3a_debug_set(b"gemm256_persist", 1)
+        lib.q3a_debug_set(b"gemm256_min_tiles", 128)
+
+
 def test_gemm256_persistent_walk_is_bit_identical_to_one_workgroup_per_tile():
     """k_gemm256.hip, round 6: a launch of more tiles than CUs is min(tiles, CUs) workgroups that WALK the tiles, the next tile's first
     K tile arriving under the epilogue (staging halved to 8 KiB per wave, four 32-row passes); knob gemm256_persist = 0 launches one
