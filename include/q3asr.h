@@ -274,6 +274,8 @@ int32_t q3a_capitalize_first(const char* s, char* out, int32_t cap);
  *   "gemm256_persist"    1 (default): a gemm256 launch is min(tiles, CUs) workgroups that walk the tiles of their XCD's chunk, the next
  *                        tile's first K tile arriving under the epilogue; 0: one workgroup per tile; n > 1: a walk of exactly n workgroups (tests).
  *                        Same arithmetic: bit-identical.
+ *   "gemm256_group_m"    gemm256's tile order: groups of this many tile rows, M fastest inside a group (1 = N fastest over the whole
+ *                        matrix; 0, the default = 8 where the matrix is at least 8 tiles wide, else 1).  The same tiles assigned to other workgroups: bit-identical.
  *   "dattn_batched_min_wgs"  sequences x kv heads of a decode group from which the batched decode step uses the
  *                        one-workgroup-per-(sequence, kv head) attention kernel (k_dattn.hip) instead of key splits + merge.
  *   "decode_group_size"  sequences per group of the batched decode step (1..32; 0 = 32), taken at the next prefill.

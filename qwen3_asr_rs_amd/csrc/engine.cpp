@@ -106,6 +106,7 @@ Knobs& knobs() {
     auto env = [](const char* name, std::atomic<int>& dst) { if (const char* e = getenv(name)) dst.store(atoi(e)); };
     env("Q3A_GEMM256_MIN_TILES", k.gemm256_min_tiles);
     env("Q3A_GEMM256_PERSIST", k.gemm256_persist);
+    env("Q3A_GEMM256_GROUP_M", k.gemm256_group_m);
     env("Q3A_DATTN_BATCHED_MIN_WGS", k.dattn_batched_min_wgs);
     env("Q3A_DECODE_GROUP", k.decode_group_size);
     env("Q3A_DECODE_PARALLEL", k.decode_parallel_groups);
@@ -1689,6 +1690,7 @@ int32_t q3a_debug_set(const char* key, int32_t value) {
   Knobs& kn = knobs();
   if (strcmp(key, "gemm256_min_tiles") == 0) { kn.gemm256_min_tiles = value; return 0; }
   if (strcmp(key, "gemm256_persist") == 0) { kn.gemm256_persist = value; return 0; }
+  if (strcmp(key, "gemm256_group_m") == 0) { kn.gemm256_group_m = value; return 0; }
   if (strcmp(key, "dattn_batched_min_wgs") == 0) { kn.dattn_batched_min_wgs = value; return 0; }
   if (strcmp(key, "decode_group_size") == 0) { kn.decode_group_size = value; return 0; }
   if (strcmp(key, "decode_parallel_groups") == 0) { kn.decode_parallel_groups = value; return 0; }

@@ -31,6 +31,7 @@
 //     waits with vmcnt(0).  The barriers are raw s_barrier (a __syncthreads() would drain the DMA queue).
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "dev.h"
@@ -152,7 +153,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 template <bool GLU, class ALoader, bool ROPE = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16_t* __restrict__ Wt,
                                                          const uint16_t* __restrict__ zero, int M, int N, int K, GemmEpilogue ep,
-                                                         RopeKvArgs rk) {
+                                                         RopeKvArgs rk, int group_m) {
   __shared__ __attribute__((aligned(1024))) uint8_t lds[2 * G_BUF];  // the ONLY LDS object of this kernel
 
   const int tiles_m = (M + G_BM - 1) / G_BM, tiles_n = (N + G_BN - 1) / G_BN;
@@ -174,12 +175,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
   if (tj >= x_cnt) return;                              // (G <= tiles: never)
   int bid = x_first + tj;
   Q3A_STAMP_AT(ep.stamp, bid, 0);  // entry
-  // N fastest: the N tiles that share an A panel (the big operand when M >> N) run next to each other
+  // Tile order: groups of group_m tile rows, M fastest inside a group (group_m = 1: N fastest over the whole matrix).  The 32 tiles an
+  // XCD holds at a time are 32 consecutive ids = group_m rows x 32 / group_m columns: with 8 rows x 4 columns they share 8 A panels and 4
+  // W panels instead of 2 + 24 (gate / up: 24 column tiles) -- the XCD's L2 fetches 12 K-tile rows per step instead of 26.
+  auto tile_origin = [&](int id, int& mo, int& no) {
+    const int per_group = group_m * tiles_n, grp = id / per_group, in_g = id - grp * per_group;
+    const int first_m = grp * group_m, gsize = min(tiles_m - first_m, group_m);
+    const int tn = in_g / gsize, tm = first_m + (in_g - tn * gsize);
+    mo = tm * G_BM; no = tn * G_BN;
+  };
   int m0, n0;
-  {
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-    m0 = tm * G_BM; n0 = tn * G_BN;
-  }
+  tile_origin(bid, m0, n0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -725,10 +731,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(ALoader A, const uint16
   for (;;) {
     const int tjn = tj + wpx;
     const bool has_next = tjn < x_cnt;  // workgroup-uniform
-    {
-      const int bn = has_next ? x_first + tjn : bid, tm = bn / tiles_n, tn = bn - tm * tiles_n;
-      m0n = tm * G_BM; n0n = tn * G_BN;
-    }
+    tile_origin(has_next ? x_first + tjn : bid, m0n, n0n);
     Q3A_STAMP_AT(ep.stamp, bid, 1);  // first staging units landed: the K loop starts
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -785,7 +788,12 @@ void launch256(const ALoader& A, const uint16_t* W, const uint16_t* zero, int M,
   const int pk = knobs().gemm256_persist.load(std::memory_order_relaxed);
   const int cus = pk > 1 ? pk : device_cus();
   const int grid = pk != 0 && tiles > cus ? cus : tiles;
-  hipLaunchKernelGGL((gemm256_kernel<GLU, ALoader, ROPE>), dim3(grid), dim3(512), 0, s, A, W, zero, M, N, K, ep, rk);
+  // tile order (kernel: tile_origin): groups of 8 tile rows where the matrix is at least 8 tiles wide (qkv / fc1 / gate-up: the 32 tiles
+  // of an XCD then share 8 A + 4 W panels instead of 2 + all), N fastest where it is narrow (the convolutions: 2 column tiles, the
+  // 196 / 204-tile residual shapes: 4 -- measured: grouping them raises their memory-side traffic by 25-50 %).  Knob: 0 = this rule.
+  const int gk = knobs().gemm256_group_m.load(std::memory_order_relaxed);
+  const int gm = gk > 0 ? gk : ((N + G_BN - 1) / G_BN >= 8 ? 8 : 1);
+  hipLaunchKernelGGL((gemm256_kernel<GLU, ALoader, ROPE>), dim3(grid), dim3(512), 0, s, A, W, zero, M, N, K, ep, rk, gm);
 }
 
 }  // namespace

@@ -58,6 +58,7 @@ const char* launch_gemm16_small(const uint16_t* X, int lda, const uint16_t* W, i
 struct Knobs {
   std::atomic<int> gemm256_min_tiles{128};      // Q3A_GEMM256_MIN_TILES: 256 x 256 tiles from which gemm256 is used (k_gemm256.hip)
   std::atomic<int> gemm256_persist{1};          // Q3A_GEMM256_PERSIST: gemm256 launches min(tiles, CUs) workgroups that walk the tiles, the next tile's first K tile arriving under the epilogue (0 = one workgroup per tile, n > 1 = exactly n workgroups; bit-identical)
+  std::atomic<int> gemm256_group_m{0};          // Q3A_GEMM256_GROUP_M: gemm256's tile order -- groups of this many tile rows, M fastest inside a group (1 = N fastest over the whole matrix; 0 = 8 where the matrix is at least 8 tiles wide, else 1); the same tiles, another assignment to workgroups: bit-identical
   std::atomic<int> dattn_batched_min_wgs{128};  // Q3A_DATTN_BATCHED_MIN_WGS: S * n_kv from which launch_decode_attn_batched is used
   std::atomic<int> decode_group_size{0};        // Q3A_DECODE_GROUP: sequences per group of the batched decode step (0 = 32)
   std::atomic<int> decode_parallel_groups{1};   // Q3A_DECODE_PARALLEL: groups as parallel stream / graph branches

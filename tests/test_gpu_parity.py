@@ -370,7 +370,8 @@ def test_gemm256_persistent_walk_is_bit_identical_to_one_workgroup_per_tile():
     workgroup per tile.  Same K order and the same epilogue arithmetic, so everything downstream must agree BIT FOR BIT: 32 x 30 s
     clips at the 0.6B dimensions put every epilogue kind through tile seams -- conv2 / conv3 (implicit-GEMM loader, 6000 / 1560 tiles),
     encoder qkv / fc1 (bf16, GELU; 506 / 686), decoder qkv with the QK-norm + RoPE + cache-append epilogue (768: the KV cache the
-    decode steps read), gate / up (SwiGLU, 1224); the 196 / 204-tile residual shapes run one round either way.  Compared: audio
+    decode steps read), gate / up (SwiGLU, 1224); the 196 / 204-tile residual shapes run one round either way.  The tile ORDER (knob
+    gemm256_group_m: groups of 8 tile rows on the wide matrices by default) only changes which workgroup computes which tile.  Compared: audio
     embeddings, prefill logits, two decode steps' logits (they read the cache rows the fused epilogue wrote)."""
     from qwen3_asr_rs_amd import _lib
     from qwen3_asr_rs_amd.distributed import pack_arena_host
@@ -381,8 +382,9 @@ def test_gemm256_persistent_walk_is_bit_identical_to_one_workgroup_per_tile():
     torch.cuda.synchronize()
     got = {}
     try:
-        for persist in (0, 1):
+        for persist, group_m in ((0, 0), (1, 0), (1, 1), (0, 8)):  # (group_m: the tile ORDER -- 0 = by rule, 1 = N fastest, 8 = groups of 8 tile rows everywhere)
             assert lib.q3a_debug_set(b"gemm256_persist", persist) == 0
+            assert lib.q3a_debug_set(b"gemm256_group_m", group_m) == 0
             eng = HipEngine(d, 0, max_new_tokens=8, device_arena=(arena.data_ptr(), arena.numel()))
             eng.mel(clips)
             emb = np.concatenate([e.ravel() for e in eng.encode()])
@@ -391,12 +393,14 @@ def test_gemm256_persistent_walk_is_bit_identical_to_one_workgroup_per_tile():
             eng.set_next_tokens([11 + 3 * i for i in range(32)])
             lg1, _, _ = eng.decode_step()
             lg2, nx, _ = eng.decode_step()
-            got[persist] = (emb, logits.copy(), lg1.copy(), lg2.copy(), nx.copy())
+            got[(persist, group_m)] = (emb, logits.copy(), lg1.copy(), lg2.copy(), nx.copy())
             eng.close()
     finally:
         lib.q3a_debug_set(b"gemm256_persist", 1)
-    for a, b in zip(got[0], got[1]):
-        assert np.isfinite(a).all() and np.array_equal(a, b), float(np.abs(a.astype(np.float64) - b).max())
+        lib.q3a_debug_set(b"gemm256_group_m", 0)
+    for key in ((1, 0), (1, 1), (0, 8)):
+        for a, b in zip(got[(0, 0)], got[key]):
+            assert np.isfinite(a).all() and np.array_equal(a, b), (key, float(np.abs(a.astype(np.float64) - b).max()))
 
 
 def test_mfma_attention_matches_valu_attention(tiny_dir):

@@ -46,7 +46,7 @@ def main():
     env_keys = sorted({k for _, kv in parsed for k in kv if k.isupper()})
     # defaults of every key that some setting touches (restored between settings)
     known = {"skinny_glu_hp3": 1, "dattn_batched_min_wgs": 128, "skinny_q": 1, "eos_run_ahead": 1,
-             "decode_group_size": 0, "decode_parallel_groups": 1, "fuse_qkrope": 1, "gemm256_min_tiles": 128, "gemm256_persist": 1}
+             "decode_group_size": 0, "decode_parallel_groups": 1, "fuse_qkrope": 1, "gemm256_min_tiles": 128, "gemm256_persist": 1, "gemm256_group_m": 0}
     for _, kv in parsed:
         for k in kv:
             if k.isupper():

@@ -20,7 +20,11 @@ step mfma_table
   timeout 200 rocprofv3 --kernel-trace --stats -d $R/$out/trc -o t -- env PMC_BATCH=32 python $R/tools/pmc_target_enc.py > $R/$out/trc.log 2>&1 )
 python tools/mfma_table.py --pmc $(find $out/pmcb -name "*_results.db" | head -1) --trace $(find $out/trc -name "*_results.db" | head -1) --batch 32 > $out/${r}_mfma_table_b32.txt 2>&1
 python tools/pmc_kernels.py $(find $out/pmcb -name "*_results.db" | head -1) --by-grid > $out/${r}_pmc_by_shape.txt 2>&1
-rm -rf $out/pmcb $out/trc
+# memory-side traffic of the same launches per shape (separate FETCH_SIZE / WRITE_SIZE passes)
+( cd /tmp && export TMPDIR=/tmp
+  for c in FETCH_SIZE WRITE_SIZE; do timeout 300 rocprofv3 --pmc $c --kernel-trace -d $R/$out/tr_$c -o t -- env PMC_BATCH=32 python $R/tools/pmc_target_enc.py > $R/$out/tr_$c.log 2>&1; done )
+python tools/gemm_traffic.py --fetch $(find $out/tr_FETCH_SIZE -name "*_results.db" | head -1) --write $(find $out/tr_WRITE_SIZE -name "*_results.db" | head -1) --batch 32 > $out/${r}_gemm256_hbm_traffic_by_shape.txt 2>&1
+rm -rf $out/pmcb $out/trc $out/tr_FETCH_SIZE $out/tr_WRITE_SIZE
 step phase_probe
 timeout 120 tools/bin/phase_probe layer,one > $out/${r}_phase_probe_decode_layers.txt 2>&1
 step streams

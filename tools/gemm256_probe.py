@@ -15,9 +15,10 @@ from qwen3_asr_rs_amd.engine import selftest_gemm16  # noqa: E402
 lib = _lib.load()
 
 
-def use256(on: bool, persist: int = 1):
+def use256(on: bool, persist: int = 1, group_m: int = 0):
     assert lib.q3a_debug_set(b"gemm256_min_tiles", 0 if on else 1 << 30) == 0
     assert lib.q3a_debug_set(b"gemm256_persist", persist) == 0
+    assert lib.q3a_debug_set(b"gemm256_group_m", group_m) == 0
 
 
 def main():
@@ -47,15 +48,15 @@ def main():
                ("4096^3", 4096, 4096, 4096), ("8192^3", 8192, 8192, 8192)]
     for name, M, N, K in tshapes:
         res = {}
-        for tag, on, persist in (("old", False, 1), ("p0", True, 0), ("p1", True, 1), ("p0b", True, 0), ("p1b", True, 1)):
-            use256(on, persist)
+        for tag, on, persist, gm in (("old", False, 1, 0), ("p0", True, 0, 0), ("p1", True, 1, 0), ("g1", True, 1, 1), ("p0b", True, 0, 0), ("p1b", True, 1, 0), ("g1b", True, 1, 1)):
+            use256(on, persist, gm)
             r = selftest_gemm16(M, N, K, reps=10 if K * M * N > 3e11 else 30)
             res[tag] = r["tflops_bf16"]
             if r["err"] > 2e-5 * max(r["ref_max"], 1.0):
                 bad += 1
                 print(f"  {name}: {tag} WRONG err {r['err']:.3e}")
         us = lambda tf: 2.0 * M * N * K / (tf * 1e12) * 1e6
-        print(f"  {name:14s} M={M:6d} N={N:5d} K={K:5d}: old {res['old']:7.1f}   one-per-tile {res['p0']:7.1f} / {res['p0b']:7.1f}   persistent {res['p1']:7.1f} / {res['p1b']:7.1f} TFLOP/s"
+        print(f"  {name:14s} M={M:6d} N={N:5d} K={K:5d}: old {res['old']:7.1f}   one-per-tile {res['p0']:7.1f} / {res['p0b']:7.1f}   persistent {res['p1']:7.1f} / {res['p1b']:7.1f}   persistent, N-fastest order {res['g1']:7.1f} / {res['g1b']:7.1f} TFLOP/s"
               f"   ({us(max(res['p0'], res['p0b'])):7.1f} -> {us(max(res['p1'], res['p1b'])):7.1f} us)")
     use256(True, 1)
     print("FAILURES:", bad)
