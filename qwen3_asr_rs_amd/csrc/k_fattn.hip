@@ -26,6 +26,29 @@
 namespace q3a {
 namespace {
 
+// Workgroup -> (query tile, kv head, segment).  The query tiles of one (segment, kv head) read the same K / V rows; with the plain
+// blockIdx mapping their linear ids are consecutive, and the dispatcher deals consecutive workgroups to DIFFERENT XCDs -- at 32 clips
+// the prefill's 7 query tiles per head sit on 7 XCDs, each XCD's L2 fetches the head's K / V for itself (round 6, from the memory-side
+// counters: the launch moved several times its operands through the fabric).  Bijective remap (performance only; any placement is
+// correct): workgroup b, on XCD b % 8, takes the (b / 8)-th triple of that XCD's contiguous chunk of the x-fastest order, so the
+// query tiles of a head are neighbours ON ONE XCD and its K / V rows are fetched once per XCD.  -DQ3A_FATTN_XCD_REMAP=0: plain mapping.
+#ifndef Q3A_FATTN_XCD_REMAP
+#define Q3A_FATTN_XCD_REMAP 1
+#endif
+__device__ __forceinline__ void fattn_block(int& bx, int& by, int& bz) {
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+#if Q3A_FATTN_XCD_REMAP
+  const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * (int)gridDim.z;
+  const int lin = bx + gx * (by + gy * bz);
+  const int xcd = lin & 7, loc = lin >> 3, q = total >> 3, r = total & 7;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  bx = id % gx;
+  const int t = id / gx;
+  by = t % gy;
+  bz = t / gy;
+#endif
+}
+
 template <typename KVT> struct Stage8;  // 8 consecutive head dims of one K/V row -> 8 packed bf16
 template <> struct Stage8<uint16_t> {
   static __device__ __forceinline__ uint4 load(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
@@ -61,9 +84,11 @@ __global__ __launch_bounds__(256) void fattn_kernel(AttnArgs a) {
   uint16_t* const k_lds = lds_all;
   uint16_t* const vt_lds = lds_all + KT * K_STRIDE;
 
-  const AttnSeg seg = a.segs[blockIdx.z];
-  const int kvh = blockIdx.y;
-  const int qb0 = blockIdx.x * QT;
+  int blk_x, blk_y, blk_z;
+  fattn_block(blk_x, blk_y, blk_z);
+  const AttnSeg seg = a.segs[blk_z];
+  const int kvh = blk_y;
+  const int qb0 = blk_x * QT;
   if (qb0 >= seg.len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
@@ -309,9 +334,11 @@ __global__ __launch_bounds__(256, NS == 3 ? 3 : 2) void fattn_dma_kernel(AttnArg
   static_assert(PPW >= 1, "tile too small for four waves");
   __shared__ __attribute__((aligned(1024))) uint8_t ring[NS * STAGE];  // the ONLY LDS object: [stage][K | V][row][HD]
 
-  const AttnSeg seg = a.segs[blockIdx.z];
-  const int kvh = blockIdx.y;
-  const int qb0 = blockIdx.x * QT;
+  int blk_x, blk_y, blk_z;
+  fattn_block(blk_x, blk_y, blk_z);
+  const AttnSeg seg = a.segs[blk_z];
+  const int kvh = blk_y;
+  const int qb0 = blk_x * QT;
   if (qb0 >= seg.len) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
