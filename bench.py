@@ -778,7 +778,8 @@ def main():
                 peaks = measure_peaks(local_rank, 5)
                 peaks["what"] = ("q3a_measure_peaks (csrc/k_peaks.hip), this process, this GPU, best of 5: read-only stream over 2 GiB (16 B per lane, 8 loads in "
                                  "flight, non-temporal: the decode weight streams' access pattern), 1 GiB copy and fp32 triad (bytes counted on every "
-                                 "stream), the library's own 256x256x64 bf16 GEMM on 8192^3; nominal: 8000 GB/s, 2500 TFLOP/s dense bf16")
+                                 "stream), the library's own 256x256x64 bf16 GEMM on 8192^3 -- on constant operands (mfma_bf16_TFLOPs: nothing toggles, the clock "
+                                 "stays high: the ceiling) and on random ones (mfma_bf16_TFLOPs_random_data: what real data draws); nominal: 8000 GB/s, 2500 TFLOP/s dense bf16")
             except Exception as ex:  # noqa: BLE001
                 peaks = {"error": str(ex)[:200]}
         roof = roofline_block(args.preset, B, args.seconds, args.new_tokens, args.precise, args.ckpt_dir, dims, ab, dec_us, stream_prof,

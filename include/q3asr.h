@@ -216,13 +216,14 @@ int32_t q3a_profile_weight_stream(q3a_engine* e, int32_t reps, float* avg_us, do
 
 /* Measured denominators for the roofline fractions (SURVEY.md section 8d "Peaks to divide by: measure on the box"; csrc/k_peaks.hip):
  * a read-only HBM stream over 2 GiB (the access pattern of the decode-step weight streams), a 1 GiB device copy and a triad
- * (bytes counted on every stream they touch), and the library's own 256x256x64 bf16 GEMM on 8192^3 -- each the best of `reps`
+ * (bytes counted on every stream they touch), and the library's own 256x256x64 bf16 GEMM on 8192^3, once on constant and once on random operands -- each the best of `reps`
  * launches between two HIP events.  Needs 2 GiB of free device memory; not on the product path. */
 typedef struct q3a_peaks {
   double hbm_read_gbps, hbm_copy_gbps, hbm_triad_gbps; /* GB/s (1e9 bytes per second) */
   double hbm_read_bytes;                                /* bytes one read sweep covers */
-  double mfma_bf16_tflops;                              /* 2 M N K / time */
-  int32_t gemm_m, gemm_n, gemm_k, n_cu, reps, reserved[3];
+  double mfma_bf16_tflops;                              /* 2 M N K / time, operands = one constant (the chip's clock stays high: the ceiling) */
+  int32_t gemm_m, gemm_n, gemm_k, n_cu, reps, reserved;
+  double mfma_bf16_tflops_random;                       /* the same GEMM on random operands (sign + mantissa bits toggling: what real data draws; the chip clocks down) */
 } q3a_peaks;
 int32_t q3a_measure_peaks(int32_t device, int32_t reps, q3a_peaks* out);
 

@@ -26,7 +26,7 @@ SYMBOLS = [
 class Peaks(C.Structure):
     _fields_ = [("hbm_read_gbps", C.c_double), ("hbm_copy_gbps", C.c_double), ("hbm_triad_gbps", C.c_double), ("hbm_read_bytes", C.c_double),
                 ("mfma_bf16_tflops", C.c_double), ("gemm_m", C.c_int32), ("gemm_n", C.c_int32), ("gemm_k", C.c_int32), ("n_cu", C.c_int32),
-                ("reps", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("reps", C.c_int32), ("reserved", C.c_int32), ("mfma_bf16_tflops_random", C.c_double)]
 
 
 class Opts(C.Structure):

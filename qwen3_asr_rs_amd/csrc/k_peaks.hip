@@ -7,7 +7,8 @@
 //                a grid-stride and a contiguous-span form at 4 / 8 / 16 workgroups per CU;
 //   * hbm_copy   1 GiB -> 1 GiB (bytes counted both ways), the "device memcpy" number;
 //   * hbm_triad  a = b + s * c over three 680 MiB arrays of fp32 (bytes counted three ways);
-//   * mfma_bf16  the product's own 256 x 256 x 64 bf16 GEMM (k_gemm256.hip) on 8192^3 with a bf16 output: 2 M N K / time.
+//   * mfma_bf16  the product's own 256 x 256 x 64 bf16 GEMM (k_gemm256.hip) on 8192^3 with a bf16 output: 2 M N K / time -- on constant
+//                operands (the ceiling: nothing toggles, the clock stays high) and on random ones (what real data draws).
 // Each is the BEST of `reps` timed launches between two HIP events after one warm-up launch.  None of this is on the product
 // path; nothing here is used to compute a transcript.
 #include <hip/hip_runtime.h>
@@ -24,6 +25,15 @@ namespace q3a {
 namespace {
 
 constexpr int PK_UNROLL = 8;
+
+// bf16 values with a random sign and random mantissa, magnitudes in [0.5, 1) (integer hash of the element index)
+__global__ __launch_bounds__(256) void peak_fill_random_kernel(uint16_t* __restrict__ p, size_t n, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    unsigned h = (unsigned)i * 2654435761u ^ (unsigned)(i >> 32) ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    p[i] = (uint16_t)(0x3f00u | (h & 0x7fu) | ((h & 0x80u) << 8));
+  }
+}
 
 // grid-stride over 16-byte words; every lane keeps PK_UNROLL independent loads in flight
 __global__ __launch_bounds__(256) void peak_read_kernel(const uint4* __restrict__ src, size_t n16, unsigned* __restrict__ sink) {
@@ -178,6 +188,13 @@ extern "C" int32_t q3a_measure_peaks(int32_t device, int32_t reps, q3a_peaks* ou
     if (kerr || ms <= 0.f) return 1;
     out->mfma_bf16_tflops = 2.0 * M * (double)N * K / (ms * 1e-3) / 1e12;
     out->gemm_m = M; out->gemm_n = N; out->gemm_k = K;
+    // the same launch on random operands: the matrix pipes' power follows the bits that toggle, and under it the chip clocks down
+    // (k_gemm256's probe: 1.10-1.16 PFLOP/s on random data where the constant-operand run above reaches 1.4-1.65) -- the
+    // denominator to hold real-data GEMM launches against
+    hipLaunchKernelGGL(peak_fill_random_kernel, dim3(n_cu * 8), dim3(256), 0, s, X, (size_t)M * K + (size_t)N * K, 0x9e3779b9u);
+    const float msr = best_ms([&] { if (const char* e = launch_gemm256(X, K, W, M, N, K, ep, false, s)) kerr = e; });
+    if (kerr || msr <= 0.f) return 1;
+    out->mfma_bf16_tflops_random = 2.0 * M * (double)N * K / (msr * 1e-3) / 1e12;
   }
   if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return 1;
   out->n_cu = n_cu;

@@ -309,7 +309,7 @@ def measure_peaks(device: int = 0, reps: int = 5) -> dict:
     if lib.q3a_measure_peaks(device, reps, C.byref(pk)) != 0:
         raise RuntimeError("q3a_measure_peaks failed (no HIP device, or less than 2 GiB of free device memory)")
     return {"hbm_read_GBps": round(pk.hbm_read_gbps, 1), "hbm_copy_GBps": round(pk.hbm_copy_gbps, 1), "hbm_triad_GBps": round(pk.hbm_triad_gbps, 1),
-            "mfma_bf16_TFLOPs": round(pk.mfma_bf16_tflops, 1), "gemm": [pk.gemm_m, pk.gemm_n, pk.gemm_k], "read_sweep_bytes": int(pk.hbm_read_bytes),
+            "mfma_bf16_TFLOPs": round(pk.mfma_bf16_tflops, 1), "mfma_bf16_TFLOPs_random_data": round(pk.mfma_bf16_tflops_random, 1), "gemm": [pk.gemm_m, pk.gemm_n, pk.gemm_k], "read_sweep_bytes": int(pk.hbm_read_bytes),
             "n_cu": pk.n_cu, "best_of": pk.reps}
 
 

@@ -66,6 +66,8 @@ def test_measured_peaks_are_plausible():
     assert 2600 < pk["hbm_read_GBps"] <= 8000, pk
     assert 1500 < pk["hbm_copy_GBps"] <= 1.2 * pk["hbm_read_GBps"] and 1500 < pk["hbm_triad_GBps"] <= 1.2 * pk["hbm_read_GBps"], pk
     assert 750 < pk["mfma_bf16_TFLOPs"] <= 2500 and pk["gemm"] == [8192, 8192, 8192] and pk["n_cu"] >= 64, pk
+    # the same GEMM on random operands: slower (the chip clocks down under the toggling bits), never faster than the constant-operand run by more than noise
+    assert 600 < pk["mfma_bf16_TFLOPs_random_data"] <= 1.05 * pk["mfma_bf16_TFLOPs"], pk
 
 
 def test_mel_reference_clips_and_hf_golden(tiny_dir):
