@@ -27,8 +27,10 @@
 //     is re-staged >= 2 phases after its last read (WAR, the groups being one barrier apart) and waited for with a
 //     COUNTED vmcnt one phase before it is read (RAW: wait -> barrier -> read):
 //         P1(t) stages B-n1(t+1)   P2(t) stages A-m1(t+1)   P3(t) stages A-m0(t+2)   P4(t) stages B-n0(t+2)
-//     so four units (8 DMA instructions per wave, 64 KiB per CU) are always in flight and nothing but the last tile ever
-//     waits with vmcnt(0).  The barriers are raw s_barrier (a __syncthreads() would drain the DMA queue).
+//     so four units (8 DMA instructions per wave, 64 KiB per CU) are always in flight and nothing in the K loop ever
+//     waits with vmcnt(0).  The barriers are raw s_barrier (a __syncthreads() would drain the DMA queue);
+//   * round 6: a launch is min(tiles, CUs) PERSISTENT workgroups that walk the tiles, the K-tile stream running on across
+//     output tiles (comment at the kernel), in a tile order chosen for the XCDs' L2s (launch256).
 #include <stdlib.h>
 
 #include <algorithm>
@@ -136,8 +138,8 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // qknorm_rope_kv_kernel (k_decode.hip) as its epilogue -- see the epilogue below.
 //
 // PERSISTENT TILE LOOP (round 6).  The grid is min(tiles, CUs) workgroups; workgroup b (XCD b % 8 under round-robin dispatch) walks
-// the tiles loc, loc + w, loc + 2 w, ... of ITS XCD's contiguous chunk of the N-fastest tile order (w = workgroups on that XCD), so
-// the tiles an XCD holds at any time are still neighbours in its L2.  The K-tile stream does not stop at an output tile's end: the
+// the tiles loc, loc + w, loc + 2 w, ... of ITS XCD's contiguous chunk of the tile order (tile_origin below; w = workgroups on that
+// XCD), so the tiles an XCD holds at any time are consecutive in that order: neighbours in its L2.  The K-tile stream does not stop at an output tile's end: the
 // staging slots of the last two K tiles of tile i, which used to stay empty (the N1 / N2 = false tails), carry K tile 0 of tile
 // i + 1 -- the per-lane row pointers are re-initialised in place right behind their last use for tile i -- so tile i + 1's 64 KiB
 // land UNDER tile i's epilogue, and the epilogue's stores drain under tile i + 1's first K tiles instead of in front of a workgroup
